@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- find_arb! sweep throughput on MI355X (BASELINE.json metric), one JSON line.
+
+A "step" is ONE materialising find_arb! sweep over the workload's pools at a fixed price vector:
+every pool's closed-form arbitrage is solved, Δ/Λ are written to HBM, and Ψ (netflows) plus the
+dual scalar are reduced -- the work of `find_arb!(r, v)` + the scatter loops of `fn`/`g!`
+(src/router.jl:38-42, :79-83, :98-100).  Inputs (pools, v) are resident in HBM before the timed
+region; at N>1 every rank sweeps its own shard of the same size (weak scaling) and the ranks
+all-reduce the n_tokens+1 doubles {Ψ, acc} over RCCL once per step.
+
+    python bench.py [--gpus N --steps K --warmup W --workload config3]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Extra keys on the line: roofline (dominant kernel, HIP events around every sweep launch in the
+timed region), cpu_baseline (the C oracle on the host cores, bounded sample), route (route!
+wall-clock on the same market, GPU vs the CPU restatement, and their netflow parity).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from cfmmrouter_amd._lib import KIND_GEOMEAN, KIND_PRODUCT, KIND_UNIV3
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic bytes per pool-evaluation, materialising sweep (SURVEY.md §8d / DESIGN.md):
+#   read pool state + write Δ(16 B) + Λ(16 B)
+ALG_BYTES = {KIND_PRODUCT: 32 + 32, KIND_GEOMEAN: 48 + 32}
+ALG_BYTES_FUSED = {KIND_PRODUCT: 32, KIND_GEOMEAN: 48}
+
+
+def alg_bytes(batches, materialize=True):
+    tot = 0
+    for b in batches:
+        if b.kind == KIND_UNIV3:  # 32 B header + 16 B per tick (+ 32 B of trades)
+            tot += len(b) * 32 + 16 * b.lower_ticks.size + (32 * len(b) if materialize else 0)
+        else:
+            tot += len(b) * (ALG_BYTES if materialize else ALG_BYTES_FUSED)[b.kind]
+    return tot
+
+
+WORKLOADS = {
+    # name: (description, n_tokens, builder(rank) -> [PoolBatch], objective builder)
+    "config2": ("100k ProductTwoCoin pools, 64 tokens, LinearNonnegative arbitrage", 64,
+                lambda rank: [synth.product_pools(100_000, 64, seed=1234, first=rank * 100_000)]),
+    "config3": ("1M mixed ProductTwoCoin + GeometricMeanTwoCoin pools (500k each), 256 tokens, "
+                "LinearNonnegative arbitrage", 256,
+                lambda rank: [synth.product_pools(500_000, 256, seed=1234, first=rank * 500_000),
+                              synth.geomean_pools(500_000, 256, seed=1234, first=rank * 500_000)]),
+    "config4shard": ("500k ProductTwoCoin pools per GPU (4M over 8 GPUs), 512 tokens", 512,
+                     lambda rank: [synth.product_pools(500_000, 512, seed=1234, first=rank * 500_000)]),
+    "config5": ("1M BoundedProduct (2-tick UniV3) pools, 256 tokens, BasketLiquidation", 256,
+                lambda rank: [synth.bounded_product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
+    "product1m": ("1M ProductTwoCoin pools, 256 tokens, LinearNonnegative arbitrage", 256,
+                  lambda rank: [synth.product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
+}
+
+
+def objective_for(name, n):
+    if name == "config5":
+        return cr.BasketLiquidation(1, synth.basket(n, seed=1234))
+    return cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
+
+
+def cpu_baseline(batches, n, v, budget_s=12.0):
+    """The oracle's find_arb! sweep (OpenMP over pools, like Threads.@threads) followed by the
+    reference's two SERIAL reductions (src/router.jl:81-83, :98-100), timed on the host cores."""
+    from oracle import cfmm_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_poolset
+
+    ps = oracle_poolset(batches, n)
+    threads = orc.lib().oracle_max_threads()
+    m = ps.m
+    reps, t_tot = 0, 0.0
+    ps.sweep(v, threads)  # warm caches / thread pool
+    while t_tot < budget_s and reps < 200:
+        t0 = time.perf_counter()
+        D, L = ps.sweep(v, threads)
+        orc.dual_acc(D, L, ps.Ai, v)
+        G = np.zeros(n)
+        orc.grad_scatter(G, D, L, ps.Ai)
+        t_tot += time.perf_counter() - t0
+        reps += 1
+    return {"value": m * reps / t_tot, "unit": "pool-evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"{reps} full sweeps of the same {m}-pool workload (oracle/cfmm_oracle.c: OpenMP sweep + "
+                      f"serial dual/gradient reductions), {t_tot:.1f} s of host time; the Julia reference itself "
+                      f"cannot run here (no Julia toolchain)"}
+
+
+def route_leg(name, batches, n, budget_s=60.0):
+    """route! wall-clock on the workload: GPU path vs the CPU restatement, and netflow parity."""
+    from oracle import cfmm_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_objective, oracle_poolset
+
+    obj = objective_for(name, n)
+    v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
+    r = cr.Router(obj, batches, n, device=torch.cuda.current_device())
+    cr.route_(r, v=v0)  # warm
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cr.route_(r, v=v0)
+        times.append(time.perf_counter() - t0)
+    psi = cr.netflows(r)
+    sweeps = r.info.get("funcalls")
+    r.close()
+    out = {"gpu_ms": 1e3 * min(times), "evaluations": sweeps}
+    t0 = time.perf_counter()
+    ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(batches, n), v0=v0,
+                           nthreads=orc.lib().oracle_max_threads())
+    out["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
+    out["cpu_evaluations"] = ref["info"]["funcalls"]
+    out["netflow_rel_err"] = float(np.max(np.abs(psi - ref["psi"])) / np.max(np.abs(ref["psi"])))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and route legs")
+    ap.add_argument("--fused", action="store_true", help="time the fused evaluation (no Δ/Λ write-back)")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    desc, n, build = WORKLOADS[args.workload]
+    batches = build(rank)
+    m_rank = sum(len(b) for b in batches)
+    v = synth.sweep_prices(n, seed=1234)
+    be = cr.DeviceBackend(n, batches, device=local_rank)
+    for kv in args.opt:
+        k, val = kv.split("=")
+        be.ctx.set_option(k, int(val))
+    stream = torch.cuda.current_stream()
+    be.ctx.set_stream(stream.cuda_stream)
+    v_t = torch.from_numpy(v).to("cuda")
+    out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    materialize = not args.fused
+
+    def step():
+        be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+        if world > 1:
+            dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
+
+    for _ in range(args.warmup):
+        step()
+    be.ctx.set_option("time_kernels", 1)
+    be.ctx.kernel_times()  # reset
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kt = be.ctx.kernel_times()
+    be.ctx.set_option("time_kernels", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the timed path produced the oracle's netflows (spot check on rank 0, small sample)
+    psi_dev = out_t.cpu().numpy()
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * m_rank * args.steps / elapsed
+    bytes_per_launch = alg_bytes(batches, materialize)
+    sweep_ms = kt["sweep_ms"] / max(args.steps, 1)  # all sweep launches of one step
+    achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(args.workload + ("_fused" if args.fused else ""))
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "find_arb! pool-evaluations/sec (materialising sweep + Ψ/dual reduction)",
+        "value": value, "unit": "pool-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
+                   "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
+                   "sharding": f"pools x{world}, all-reduce of n_tokens+1 f64 per step" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "cfmm::sweep_kernel (all segment launches of one step)",
+                     "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": sweep_ms,
+                     "reduce_kernel_ms": kt["reduce_ms"] / max(args.steps, 1)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(batches, n, v)
+        # check the device result of the timed path against the oracle's netflows
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import oracle_sweep
+        _, _, psio, acco = oracle_sweep(batches, n, v, nthreads=8)
+        line["parity"] = {"netflow_rel_err_at_fixed_v": float(np.max(np.abs(psi_dev[:n] - psio)) / np.max(np.abs(psio))),
+                          "dual_rel_err": float(abs(psi_dev[n] - acco) / max(abs(acco), 1.0))}
+        try:
+            line["route"] = route_leg(args.workload, batches, n)
+        except Exception as e:  # the route leg is informational; never lose the bench line over it
+            line["route"] = {"error": repr(e)}
+    be.close()
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+"""ctypes binding of libcfmm_amd.so (include/cfmm_amd.h).
+
+This is the only door from the Python host mirror into the device code.  There is NO fallback:
+if the shared library is missing or no gfx950 device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfmm_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_HIP = -2
+ERR_STATE = -3
+ERR_UNSUPPORTED = -4
+
+KIND_PRODUCT, KIND_GEOMEAN, KIND_UNIV3 = 0, 1, 2
+
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+
+class ArgumentError(ValueError):
+    """The reference's ArgumentError (src/cfmms.jl:77-78, src/objectives.jl:54,97)."""
+
+
+class CFMMDeviceError(RuntimeError):
+    """A HIP runtime failure or a missing device/extension."""
+
+
+def build(force: bool = False) -> str:
+    """Compile libcfmm_amd.so for gfx950 with hipcc (csrc/Makefile)."""
+    srcs = [os.path.join(CSRC, f) for f in ("sweep_kernels.hip", "cfmm_abi.hip", "sweep.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "cfmm_amd.h"))
+    stale = not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the extension (once).  Raises CFMMDeviceError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CFMMDeviceError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cfmmrouter.jl_amd/csrc`).  There is no CPU fallback.")
+    # One HIP runtime per process: if torch is going to be used (streams, torch.distributed), its
+    # bundled libamdhip64 must be the one that is loaded, so import it before our library.
+    if "torch" not in sys.modules and os.environ.get("CFMM_AMD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH)
+    L.cfmm_ctx_create.argtypes = [C.c_int, C.c_int32, C.POINTER(_ctx)]
+    L.cfmm_ctx_destroy.argtypes = [_ctx]
+    L.cfmm_ctx_destroy.restype = None
+    L.cfmm_last_error.argtypes = [_ctx]
+    L.cfmm_last_error.restype = C.c_char_p
+    L.cfmm_version.restype = C.c_char_p
+    L.cfmm_set_stream.argtypes = [_ctx, C.c_void_p]
+    L.cfmm_set_option.argtypes = [_ctx, C.c_char_p, C.c_int64]
+    L.cfmm_get_option.argtypes = [_ctx, C.c_char_p, _i64p]
+    L.cfmm_pools_add_product.argtypes = [_ctx, C.c_int64, _f64p, _f64p, _i32p]
+    L.cfmm_pools_add_geomean.argtypes = [_ctx, C.c_int64, _f64p, _f64p, _f64p, _i32p]
+    L.cfmm_pools_add_univ3.argtypes = [_ctx, C.c_int64, _f64p, _f64p, _i32p, _i64p, _f64p, _f64p]
+    L.cfmm_pools_clear.argtypes = [_ctx]
+    L.cfmm_pools_count.argtypes = [_ctx]
+    L.cfmm_pools_count.restype = C.c_int64
+    L.cfmm_n_tokens.argtypes = [_ctx]
+    L.cfmm_n_tokens.restype = C.c_int32
+    L.cfmm_find_arb.argtypes = [_ctx, _f64p]
+    L.cfmm_eval.argtypes = [_ctx, _f64p, _f64p, _f64p]
+    L.cfmm_get_trades.argtypes = [_ctx, _f64p, _f64p]
+    L.cfmm_get_trades_range.argtypes = [_ctx, C.c_int32, C.c_int64, C.c_int64, _f64p, _f64p]
+    L.cfmm_netflows.argtypes = [_ctx, _f64p]
+    L.cfmm_dual_value.argtypes = [_ctx, _f64p]
+    L.cfmm_sweep_dev.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_int]
+    L.cfmm_trades_dev.argtypes = [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.cfmm_kernel_times.argtypes = [_ctx, _i64p, _f64p, _i64p, _f64p]
+    L.cfmm_segment_count.argtypes = [_ctx]
+    L.cfmm_segment_count.restype = C.c_int32
+    L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p]
+    _lib = L
+    return L
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def ptr(a):
+    if a is None:
+        return None
+    if a.dtype == np.float64:
+        return a.ctypes.data_as(_f64p)
+    if a.dtype == np.int32:
+        return a.ctypes.data_as(_i32p)
+    if a.dtype == np.int64:
+        return a.ctypes.data_as(_i64p)
+    raise TypeError(a.dtype)
+
+
+class Context:
+    """RAII wrapper of a cfmm_ctx (one device, one pool store)."""
+
+    def __init__(self, n_tokens: int, device: int = 0):
+        self._L = lib()
+        h = _ctx()
+        rc = self._L.cfmm_ctx_create(int(device), int(n_tokens), C.byref(h))
+        if rc != OK:
+            self._h = None
+            self._raise(rc, None)
+        self._h = h
+        self.n_tokens = int(n_tokens)
+        self.device = int(device)
+
+    # -- errors --------------------------------------------------------------------------------
+    def _raise(self, rc, h):
+        msg = self._L.cfmm_last_error(h).decode()
+        if rc == ERR_INVALID_ARG:
+            raise ArgumentError(msg)
+        if rc == ERR_STATE:
+            raise RuntimeError(msg)
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise CFMMDeviceError(msg)
+
+    def _check(self, rc):
+        if rc != OK:
+            self._raise(rc, self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfmm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._check(self._L.cfmm_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.cfmm_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        self._check(self._L.cfmm_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # -- pools ---------------------------------------------------------------------------------
+    def add_product(self, R, gamma, Ai0):
+        R, gamma = f64(R), f64(gamma)
+        Ai0 = np.ascontiguousarray(Ai0, dtype=np.int32)
+        m = gamma.size
+        if R.size != 2 * m or Ai0.size != 2 * m:
+            raise ArgumentError("R and Ai must have shape [m, 2]")
+        self._check(self._L.cfmm_pools_add_product(self._h, m, ptr(R), ptr(gamma), ptr(Ai0)))
+
+    def add_geomean(self, R, w, gamma, Ai0):
+        R, w, gamma = f64(R), f64(w), f64(gamma)
+        Ai0 = np.ascontiguousarray(Ai0, dtype=np.int32)
+        m = gamma.size
+        if R.size != 2 * m or w.size != 2 * m or Ai0.size != 2 * m:
+            raise ArgumentError("R, w and Ai must have shape [m, 2]")
+        self._check(self._L.cfmm_pools_add_geomean(self._h, m, ptr(R), ptr(w), ptr(gamma), ptr(Ai0)))
+
+    def add_univ3(self, current_price, gamma, Ai0, tick_off, lower_ticks, liquidity):
+        current_price, gamma = f64(current_price), f64(gamma)
+        lower_ticks, liquidity = f64(lower_ticks), f64(liquidity)
+        Ai0 = np.ascontiguousarray(Ai0, dtype=np.int32)
+        tick_off = np.ascontiguousarray(tick_off, dtype=np.int64)
+        m = gamma.size
+        if current_price.size != m or Ai0.size != 2 * m or tick_off.size != m + 1:
+            raise ArgumentError("inconsistent UniV3 array sizes")
+        if m and (lower_ticks.size != tick_off[-1] or liquidity.size != tick_off[-1]):
+            raise ArgumentError("tick arrays must have tick_off[-1] entries")
+        self._check(self._L.cfmm_pools_add_univ3(self._h, m, ptr(current_price), ptr(gamma), ptr(Ai0),
+                                                 ptr(tick_off), ptr(lower_ticks), ptr(liquidity)))
+
+    def clear(self):
+        self._check(self._L.cfmm_pools_clear(self._h))
+
+    @property
+    def pool_count(self) -> int:
+        return int(self._L.cfmm_pools_count(self._h))
+
+    # -- hot path ------------------------------------------------------------------------------
+    def find_arb(self, v):
+        v = f64(v)
+        if v.size != self.n_tokens:
+            raise ArgumentError("v must have n_tokens entries")
+        self._check(self._L.cfmm_find_arb(self._h, ptr(v)))
+
+    def eval(self, v):
+        v = f64(v)
+        if v.size != self.n_tokens:
+            raise ArgumentError("v must have n_tokens entries")
+        psi = np.empty(self.n_tokens)
+        acc = C.c_double()
+        self._check(self._L.cfmm_eval(self._h, ptr(v), ptr(psi), C.byref(acc)))
+        return psi, acc.value
+
+    def trades(self):
+        m = self.pool_count
+        D, Lm = np.empty((m, 2)), np.empty((m, 2))
+        self._check(self._L.cfmm_get_trades(self._h, ptr(D), ptr(Lm)))
+        return D, Lm
+
+    def trades_range(self, seg, first, count):
+        D, Lm = np.empty((count, 2)), np.empty((count, 2))
+        self._check(self._L.cfmm_get_trades_range(self._h, int(seg), int(first), int(count), ptr(D), ptr(Lm)))
+        return D, Lm
+
+    def netflows(self):
+        psi = np.empty(self.n_tokens)
+        self._check(self._L.cfmm_netflows(self._h, ptr(psi)))
+        return psi
+
+    def dual_value(self) -> float:
+        acc = C.c_double()
+        self._check(self._L.cfmm_dual_value(self._h, C.byref(acc)))
+        return acc.value
+
+    def sweep_dev(self, d_v_ptr: int, d_out_ptr: int, materialize: bool):
+        self._check(self._L.cfmm_sweep_dev(self._h, C.c_void_p(d_v_ptr), C.c_void_p(d_out_ptr),
+                                           1 if materialize else 0))
+
+    def trades_dev(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._check(self._L.cfmm_trades_dev(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kernel_times(self):
+        sn, rn = C.c_int64(), C.c_int64()
+        sm, rm = C.c_double(), C.c_double()
+        self._check(self._L.cfmm_kernel_times(self._h, C.byref(sn), C.byref(sm), C.byref(rn), C.byref(rm)))
+        return {"sweep_launches": sn.value, "sweep_ms": sm.value, "reduce_launches": rn.value,
+                "reduce_ms": rm.value}
+
+    def segments(self):
+        out = []
+        for s in range(self._L.cfmm_segment_count(self._h)):
+            k, g, u = C.c_int32(), C.c_int32(), C.c_int32()
+            m = C.c_int64()
+            self._check(self._L.cfmm_segment_info(self._h, s, C.byref(k), C.byref(m), C.byref(g), C.byref(u)))
+            out.append({"kind": k.value, "m": m.value, "grid": g.value, "unroll": u.value})
+        return out

@@ -1,0 +1,668 @@
+// cfmm_abi.hip -- implementation of the C ABI declared in include/cfmm_amd.h.
+//
+// Host-side only: owns the HBM-resident pool store (SoA-of-pairs per pool family), the trade
+// buffers, the partial-row scratch and a pinned staging area, validates what the reference's
+// constructors validate (src/cfmms.jl:76-90) plus what its kernels silently assume
+// (src/cfmms.jl:129 "Assumes that v > 0 and γ > 0"), and launches sweep_kernels.hip.
+// There is no CPU fallback anywhere in this file: without a gfx950 device every entry point
+// that needs one fails with CFMM_ERR_HIP.
+
+#include "../../include/cfmm_amd.h"
+#include "sweep.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cfmm;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct Segment {
+    int kind = 0;
+    int64_t m = 0;
+    int64_t trade_off = 0; // first row of this segment in the trade buffers
+    int64_t n_ticks_total = 0;
+    // device arrays (owned)
+    double2* R = nullptr;
+    double2* w = nullptr;
+    double* gamma = nullptr;
+    int2* Ai = nullptr;
+    double2* pg = nullptr;
+    int2* span = nullptr;
+    int* cur_tick = nullptr;
+    double2* ticks = nullptr;
+    // launch geometry (decided at upload)
+    int grid = 0;
+    int unroll = 1;
+    int64_t row_off = 0; // first partial row
+};
+
+} // namespace
+
+struct cfmm_ctx {
+    int device = 0;
+    int n = 0;
+    int n_pad = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<Segment> segs;
+    int64_t m_total = 0;
+    int64_t rows_total = 0;
+
+    double* d_v = nullptr;        // [n]
+    double* d_out = nullptr;      // [n+1]
+    double* d_partials = nullptr; // [rows_cap][n+1]
+    int64_t rows_cap = 0;
+    double2* d_delta = nullptr;   // [trade_cap]
+    double2* d_lambda = nullptr;
+    int64_t trade_cap = 0;
+    double* h_stage = nullptr;    // pinned: [n] v in, [n+1] out
+    std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
+    bool have_out = false;
+    bool have_trades = false;
+    bool geometry_dirty = true;
+
+    // options
+    int64_t opt_max_grid = 2048;
+    int64_t opt_unroll = 0;      // 0 = auto
+    int64_t opt_bin_copies = 0;  // 0 = auto
+    int64_t opt_time_kernels = 0;
+    int64_t opt_nt_stores = 0;
+
+    // kernel timing
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Pending { hipEvent_t a, b; int what; };
+    std::vector<Pending> pending;
+    int64_t t_sweep_n = 0, t_reduce_n = 0;
+    double t_sweep_ms = 0, t_reduce_ms = 0;
+
+    mutable std::string err = "";
+};
+
+namespace {
+
+int fail(const cfmm_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(ctx, CFMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));            \
+    } while (0)
+
+template <class T>
+int upload(cfmm_ctx* c, T** dst, const void* src, size_t count)
+{
+    *dst = nullptr;
+    if (count == 0) return CFMM_OK;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(dst), count * sizeof(T)));
+    HIP_TRY(c, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return CFMM_OK;
+}
+
+void free_segment(Segment& s)
+{
+    (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
+    (void)hipFree(s.pg); (void)hipFree(s.span); (void)hipFree(s.cur_tick); (void)hipFree(s.ticks);
+    s = Segment{};
+}
+
+bool finite_pos(double x) { return std::isfinite(x) && x > 0.0; }
+
+// What two_coin_check_cast (src/cfmms.jl:76-90) enforces structurally is implied by the [m][2]
+// layout; here we check the values the closed forms assume.
+int check_two_coin(cfmm_ctx* c, int64_t m, const double* R, const double* gamma, const int32_t* Ai)
+{
+    if (m < 0) return fail(c, CFMM_ERR_INVALID_ARG, "negative pool count");
+    if (m > 0 && (!R || !gamma || !Ai)) return fail(c, CFMM_ERR_INVALID_ARG, "null pool array");
+    for (int64_t i = 0; i < m; ++i) {
+        if (!finite_pos(R[2 * i]) || !finite_pos(R[2 * i + 1]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: reserves must be finite and > 0", (long long)i);
+        if (!finite_pos(gamma[i]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: fee gamma must be finite and > 0", (long long)i);
+        const int32_t a = Ai[2 * i], b = Ai[2 * i + 1];
+        if (a < 0 || a >= c->n || b < 0 || b >= c->n)
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: token index out of range [0, %d)", (long long)i, c->n);
+        if (a == b)
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: the two token indices must differ", (long long)i);
+    }
+    return CFMM_OK;
+}
+
+// Launch geometry for a segment of m pools.
+void plan_segment(const cfmm_ctx* c, Segment& s)
+{
+    int U = (int)c->opt_unroll;
+    if (U != 1 && U != 2 && U != 4) {
+        if (s.kind == CFMM_KIND_PRODUCT) U = s.m >= (1 << 19) ? 4 : (s.m >= (1 << 18) ? 2 : 1);
+        else U = s.m >= (1 << 20) ? 2 : 1; // pow / tick walks carry more live state per pool
+    }
+    const int64_t tile = (int64_t)kBlock * U;
+    const int64_t tiles = std::max<int64_t>(1, (s.m + tile - 1) / tile);
+    s.unroll = U;
+    s.grid = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, c->opt_max_grid));
+}
+
+int bin_copies(const cfmm_ctx* c)
+{
+    if (c->opt_bin_copies == 1 || c->opt_bin_copies == kWavesPerBlock) return (int)c->opt_bin_copies;
+    // one private copy per wavefront while the block stays under 64 KiB of LDS
+    return sweep_lds_bytes(c->n_pad, kWavesPerBlock) <= 64 * 1024 ? kWavesPerBlock : 1;
+}
+
+int ensure_geometry(cfmm_ctx* c)
+{
+    if (!c->geometry_dirty) return CFMM_OK;
+    int64_t rows = 0, trades = 0;
+    for (auto& s : c->segs) {
+        plan_segment(c, s);
+        s.row_off = rows;
+        s.trade_off = trades;
+        rows += s.grid;
+        trades += s.m;
+    }
+    c->rows_total = rows;
+    c->m_total = trades;
+    if (rows > c->rows_cap) {
+        (void)hipFree(c->d_partials);
+        c->d_partials = nullptr;
+        c->rows_cap = 0;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials), (size_t)rows * (c->n + 1) * sizeof(double)));
+        c->rows_cap = rows;
+    }
+    if (trades > c->trade_cap) {
+        (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
+        c->d_delta = c->d_lambda = nullptr;
+        c->trade_cap = 0;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_delta), (size_t)trades * sizeof(double2)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_lambda), (size_t)trades * sizeof(double2)));
+        c->trade_cap = trades;
+    }
+    c->geometry_dirty = false;
+    c->have_trades = false;
+    c->have_out = false;
+    return CFMM_OK;
+}
+
+hipEvent_t take_event(cfmm_ctx* c)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+// Enqueue one full evaluation on c->stream: every segment's sweep, then the row fold.
+int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize)
+{
+    int rc = ensure_geometry(c);
+    if (rc != CFMM_OK) return rc;
+    const int copies = bin_copies(c);
+    const size_t lds = sweep_lds_bytes(c->n_pad, copies);
+    const bool timed = c->opt_time_kernels != 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (auto& s : c->segs) {
+        SweepArgs a;
+        a.v = d_v;
+        a.n = c->n;
+        a.n_pad = c->n_pad;
+        a.copies = copies;
+        a.m = s.m;
+        a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
+        a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+        a.partials = c->d_partials + (size_t)s.row_off * (c->n + 1);
+        a.nt_stores = (int)c->opt_nt_stores;
+        LaunchCfg cfg{s.grid, s.unroll, lds};
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (timed) {
+            ea = take_event(c);
+            eb = take_event(c);
+            if (ea && eb) HIP_TRY(c, hipEventRecord(ea, c->stream));
+        }
+        hipError_t e = hipSuccess;
+        switch (s.kind) {
+        case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
+        case CFMM_KIND_GEOMEAN: e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
+        case CFMM_KIND_UNIV3:
+            e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
+            break;
+        }
+        if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "sweep launch failed: %s", hipGetErrorString(e));
+        if (timed && ea && eb) {
+            HIP_TRY(c, hipEventRecord(eb, c->stream));
+            c->pending.push_back({ea, eb, 0});
+        }
+    }
+    hipEvent_t ra = nullptr, rb = nullptr;
+    if (timed) {
+        ra = take_event(c);
+        rb = take_event(c);
+        if (ra && rb) HIP_TRY(c, hipEventRecord(ra, c->stream));
+    }
+    if (c->rows_total > 0) {
+        hipError_t e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
+        if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
+    }
+    if (timed && ra && rb) {
+        HIP_TRY(c, hipEventRecord(rb, c->stream));
+        c->pending.push_back({ra, rb, 1});
+    }
+    if (materialize) c->have_trades = true;
+    return CFMM_OK;
+}
+
+int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
+{
+    if (!v) return fail(c, CFMM_ERR_INVALID_ARG, "v is null");
+    for (int j = 0; j < c->n; ++j)
+        if (!(v[j] > 0.0) || !std::isfinite(v[j]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "v[%d] must be finite and > 0 (src/cfmms.jl:129)", j);
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = enqueue_sweep(c, c->d_v, c->d_out, materialize);
+    if (rc != CFMM_OK) return rc;
+    double* h_out = c->h_stage + c->n;
+    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->last_out.assign(h_out, h_out + c->n + 1);
+    c->have_out = true;
+    return CFMM_OK;
+}
+
+int add_segment_common(cfmm_ctx* c, Segment&& s)
+{
+    c->segs.push_back(s);
+    c->geometry_dirty = true;
+    c->have_out = false;
+    c->have_trades = false;
+    return CFMM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* cfmm_version(void) { return "cfmm_amd 0.1.0 (gfx950)"; }
+
+const char* cfmm_last_error(const cfmm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
+{
+    if (!out) return fail(nullptr, CFMM_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (n_tokens < 1) return fail(nullptr, CFMM_ERR_INVALID_ARG, "n_tokens must be >= 1");
+    if (n_tokens > kMaxTokens)
+        return fail(nullptr, CFMM_ERR_UNSUPPORTED, "n_tokens %d exceeds the LDS-resident limit %d", n_tokens, kMaxTokens);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, CFMM_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count)
+        return fail(nullptr, CFMM_ERR_INVALID_ARG, "device_id %d out of range [0, %d)", device_id, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CFMM_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device_id,
+                    prop.gcnArchName);
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+
+    cfmm_ctx* c = new cfmm_ctx();
+    c->device = device_id;
+    c->n = n_tokens;
+    c->n_pad = (n_tokens + 1) & ~1;
+    auto bail = [&](int code) {
+        g_create_error = c->err;
+        cfmm_ctx_destroy(c);
+        return code;
+    };
+#define HIP_TRY_C(expr)                                                                               \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            fail(c, CFMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));                     \
+            return bail(CFMM_ERR_HIP);                                                                \
+        }                                                                                             \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY_C(prepare_kernels(std::max(sweep_lds_bytes(c->n_pad, 1), sweep_lds_bytes(c->n_pad, bin_copies(c)))));
+#undef HIP_TRY_C
+    *out = c;
+    return CFMM_OK;
+}
+
+void cfmm_ctx_destroy(cfmm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (auto& s : c->segs) free_segment(s);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int cfmm_set_stream(cfmm_ctx* c, void* hip_stream)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return CFMM_OK;
+}
+
+static int64_t* option_slot(cfmm_ctx* c, const char* key)
+{
+    if (!key) return nullptr;
+    if (!std::strcmp(key, "max_grid")) return &c->opt_max_grid;
+    if (!std::strcmp(key, "unroll")) return &c->opt_unroll;
+    if (!std::strcmp(key, "bin_copies")) return &c->opt_bin_copies;
+    if (!std::strcmp(key, "time_kernels")) return &c->opt_time_kernels;
+    if (!std::strcmp(key, "nt_stores")) return &c->opt_nt_stores;
+    return nullptr;
+}
+
+int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    int64_t* slot = option_slot(c, key);
+    if (!slot) return fail(c, CFMM_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+    if (slot == &c->opt_max_grid && value < 1) return fail(c, CFMM_ERR_INVALID_ARG, "max_grid must be >= 1");
+    if (slot == &c->opt_unroll && !(value == 0 || value == 1 || value == 2 || value == 4))
+        return fail(c, CFMM_ERR_INVALID_ARG, "unroll must be 0 (auto), 1, 2 or 4");
+    if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == kWavesPerBlock))
+        return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 or %d", kWavesPerBlock);
+    if (slot == &c->opt_bin_copies && value == kWavesPerBlock &&
+        sweep_lds_bytes(c->n_pad, kWavesPerBlock) > 160 * 1024)
+        return fail(c, CFMM_ERR_UNSUPPORTED, "bin_copies=%d does not fit LDS at n_tokens=%d", kWavesPerBlock, c->n);
+    *slot = value;
+    if (slot == &c->opt_bin_copies) {
+        hipError_t e = prepare_kernels(std::max(sweep_lds_bytes(c->n_pad, 1), sweep_lds_bytes(c->n_pad, bin_copies(c))));
+        if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "prepare_kernels: %s", hipGetErrorString(e));
+    }
+    if (slot == &c->opt_max_grid || slot == &c->opt_unroll) c->geometry_dirty = true;
+    return CFMM_OK;
+}
+
+int cfmm_get_option(const cfmm_ctx* c, const char* key, int64_t* value)
+{
+    if (!c || !value) return CFMM_ERR_INVALID_ARG;
+    int64_t* slot = option_slot(const_cast<cfmm_ctx*>(c), key);
+    if (!slot) return fail(c, CFMM_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+    *value = *slot;
+    return CFMM_OK;
+}
+
+int cfmm_pools_add_product(cfmm_ctx* c, int64_t m, const double* R, const double* gamma, const int32_t* Ai)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    int rc = check_two_coin(c, m, R, gamma, Ai);
+    if (rc != CFMM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Segment s;
+    s.kind = CFMM_KIND_PRODUCT;
+    s.m = m;
+    if ((rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.gamma, gamma, (size_t)m)) ||
+        (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
+        free_segment(s);
+        return rc;
+    }
+    return add_segment_common(c, std::move(s));
+}
+
+int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double* w, const double* gamma,
+                           const int32_t* Ai)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    int rc = check_two_coin(c, m, R, gamma, Ai);
+    if (rc != CFMM_OK) return rc;
+    if (m > 0 && !w) return fail(c, CFMM_ERR_INVALID_ARG, "null weight array");
+    for (int64_t i = 0; i < m; ++i)
+        if (!finite_pos(w[2 * i]) || !finite_pos(w[2 * i + 1]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: weights must be finite and > 0", (long long)i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    Segment s;
+    s.kind = CFMM_KIND_GEOMEAN;
+    s.m = m;
+    if ((rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.w, w, (size_t)m)) ||
+        (rc = upload(c, &s.gamma, gamma, (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
+        free_segment(s);
+        return rc;
+    }
+    return add_segment_common(c, std::move(s));
+}
+
+int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, const double* gamma,
+                         const int32_t* Ai, const int64_t* tick_off, const double* lower_ticks,
+                         const double* liquidity)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (m < 0) return fail(c, CFMM_ERR_INVALID_ARG, "negative pool count");
+    if (m > 0 && (!current_price || !gamma || !Ai || !tick_off || !lower_ticks || !liquidity))
+        return fail(c, CFMM_ERR_INVALID_ARG, "null pool array");
+    if (m > 0 && tick_off[0] != 0) return fail(c, CFMM_ERR_INVALID_ARG, "tick_off[0] must be 0");
+    const int64_t T = m > 0 ? tick_off[m] : 0;
+    if (T < 0 || T > INT32_MAX) return fail(c, CFMM_ERR_UNSUPPORTED, "total tick count must fit int32");
+    std::vector<double2> pg((size_t)m), ticks((size_t)T);
+    std::vector<int2> span((size_t)m);
+    std::vector<int> cur((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
+        if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
+        if (!finite_pos(current_price[i]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: current_price must be finite and > 0", (long long)i);
+        if (!finite_pos(gamma[i]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: fee gamma must be finite and > 0", (long long)i);
+        const int32_t a = Ai[2 * i], b = Ai[2 * i + 1];
+        if (a < 0 || a >= c->n || b < 0 || b >= c->n)
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: token index out of range [0, %d)", (long long)i, c->n);
+        if (a == b) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: the two token indices must differ", (long long)i);
+        for (int64_t j = 0; j < nt; ++j) {
+            const double t = lower_ticks[o + j], L = liquidity[o + j];
+            if (!finite_pos(t)) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: price must be finite and > 0", (long long)i, (long long)j);
+            if (j > 0 && !(t < lower_ticks[o + j - 1]))
+                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: lower_ticks must be strictly descending", (long long)i);
+            if (!(L >= 0.0) || !std::isfinite(L))
+                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: liquidity must be finite and >= 0", (long long)i, (long long)j);
+            ticks[(size_t)(o + j)] = make_double2(t, L);
+        }
+        // src/cfmms.jl:235: searchsortedlast(lower_ticks, current_price, rev=true)
+        int64_t lo = 0, hi = nt + 1;
+        while (lo < hi - 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (lower_ticks[o + mid - 1] < current_price[i]) hi = mid;
+            else lo = mid;
+        }
+        if (lo < 1)
+            return fail(c, CFMM_ERR_INVALID_ARG,
+                        "pool %lld: current_price above the first tick (the reference would index tick 0)", (long long)i);
+        pg[(size_t)i] = make_double2(current_price[i], gamma[i]);
+        span[(size_t)i] = make_int2((int)o, (int)nt);
+        cur[(size_t)i] = (int)lo;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    Segment s;
+    s.kind = CFMM_KIND_UNIV3;
+    s.m = m;
+    s.n_ticks_total = T;
+    int rc;
+    if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
+        (rc = upload(c, &s.span, span.data(), (size_t)m)) || (rc = upload(c, &s.cur_tick, cur.data(), (size_t)m)) ||
+        (rc = upload(c, &s.ticks, ticks.data(), (size_t)T))) {
+        free_segment(s);
+        return rc;
+    }
+    return add_segment_common(c, std::move(s));
+}
+
+int cfmm_pools_clear(cfmm_ctx* c)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->segs) free_segment(s);
+    c->segs.clear();
+    c->m_total = 0;
+    c->rows_total = 0;
+    c->geometry_dirty = true;
+    c->have_out = c->have_trades = false;
+    return CFMM_OK;
+}
+
+int64_t cfmm_pools_count(const cfmm_ctx* c)
+{
+    if (!c) return 0;
+    int64_t m = 0;
+    for (auto& s : c->segs) m += s.m;
+    return m;
+}
+
+int32_t cfmm_n_tokens(const cfmm_ctx* c) { return c ? c->n : 0; }
+
+int cfmm_find_arb(cfmm_ctx* c, const double* v)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    return host_sweep(c, v, true);
+}
+
+int cfmm_eval(cfmm_ctx* c, const double* v, double* psi_out, double* acc_out)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    int rc = host_sweep(c, v, false);
+    if (rc != CFMM_OK) return rc;
+    c->have_trades = false; // trades on the device no longer correspond to the latest v
+    if (psi_out) std::memcpy(psi_out, c->last_out.data(), (size_t)c->n * sizeof(double));
+    if (acc_out) *acc_out = c->last_out[(size_t)c->n];
+    return CFMM_OK;
+}
+
+int cfmm_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t count, double* Delta, double* Lambda)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb first");
+    if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+    const Segment& s = c->segs[(size_t)seg];
+    if (first < 0 || count < 0 || first + count > s.m) return fail(c, CFMM_ERR_INVALID_ARG, "row range out of bounds");
+    if (count == 0) return CFMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (Delta)
+        HIP_TRY(c, hipMemcpy(Delta, c->d_delta + s.trade_off + first, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+    if (Lambda)
+        HIP_TRY(c, hipMemcpy(Lambda, c->d_lambda + s.trade_off + first, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+    return CFMM_OK;
+}
+
+int cfmm_get_trades(cfmm_ctx* c, double* Delta, double* Lambda)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb first");
+    if (c->m_total == 0) return CFMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (Delta) HIP_TRY(c, hipMemcpy(Delta, c->d_delta, (size_t)c->m_total * sizeof(double2), hipMemcpyDeviceToHost));
+    if (Lambda) HIP_TRY(c, hipMemcpy(Lambda, c->d_lambda, (size_t)c->m_total * sizeof(double2), hipMemcpyDeviceToHost));
+    return CFMM_OK;
+}
+
+int cfmm_netflows(cfmm_ctx* c, double* psi)
+{
+    if (!c || !psi) return CFMM_ERR_INVALID_ARG;
+    if (!c->have_out) return fail(c, CFMM_ERR_STATE, "no sweep has been run yet");
+    std::memcpy(psi, c->last_out.data(), (size_t)c->n * sizeof(double));
+    return CFMM_OK;
+}
+
+int cfmm_dual_value(cfmm_ctx* c, double* acc)
+{
+    if (!c || !acc) return CFMM_ERR_INVALID_ARG;
+    if (!c->have_out) return fail(c, CFMM_ERR_STATE, "no sweep has been run yet");
+    *acc = c->last_out[(size_t)c->n];
+    return CFMM_OK;
+}
+
+int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materialize)
+{
+    if (!c || !d_v || !d_out) return CFMM_ERR_INVALID_ARG;
+    c->have_out = false; // results live on the device; the host copy is stale
+    return enqueue_sweep(c, d_v, d_out, materialize != 0);
+}
+
+int cfmm_trades_dev(cfmm_ctx* c, const double** d_delta, const double** d_lambda)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    int rc = ensure_geometry(c);
+    if (rc != CFMM_OK) return rc;
+    if (d_delta) *d_delta = reinterpret_cast<const double*>(c->d_delta);
+    if (d_lambda) *d_lambda = reinterpret_cast<const double*>(c->d_lambda);
+    return CFMM_OK;
+}
+
+int cfmm_kernel_times(cfmm_ctx* c, int64_t* sweep_launches, double* sweep_ms, int64_t* reduce_launches,
+                      double* reduce_ms)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+        if (p.what == 0) { c->t_sweep_n++; c->t_sweep_ms += ms; }
+        else { c->t_reduce_n++; c->t_reduce_ms += ms; }
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+    if (sweep_launches) *sweep_launches = c->t_sweep_n;
+    if (sweep_ms) *sweep_ms = c->t_sweep_ms;
+    if (reduce_launches) *reduce_launches = c->t_reduce_n;
+    if (reduce_ms) *reduce_ms = c->t_reduce_ms;
+    c->t_sweep_n = c->t_reduce_n = 0;
+    c->t_sweep_ms = c->t_reduce_ms = 0;
+    return CFMM_OK;
+}
+
+int32_t cfmm_segment_count(const cfmm_ctx* c) { return c ? (int32_t)c->segs.size() : 0; }
+
+int cfmm_segment_info(const cfmm_ctx* c, int32_t seg, int32_t* kind, int64_t* m, int32_t* grid, int32_t* unroll)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+    int rc = ensure_geometry(const_cast<cfmm_ctx*>(c));
+    if (rc != CFMM_OK) return rc;
+    const Segment& s = c->segs[(size_t)seg];
+    if (kind) *kind = s.kind;
+    if (m) *m = s.m;
+    if (grid) *grid = s.grid;
+    if (unroll) *unroll = s.unroll;
+    return CFMM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,66 @@
+// sweep.h -- internal C++ interface between the C ABI (cfmm_abi.hip) and the gfx950 kernels
+// (sweep_kernels.hip).  Not installed; the public surface is include/cfmm_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cfmm {
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64 lanes
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kReduceCols = 16;      // tokens per reduce block (128 B of each partial row)
+constexpr int kMaxTokens = 8192;     // v + one bin copy must fit the 160 KiB LDS of a CU
+
+// SoA-of-pairs pool stores, one struct per pool family.  All pointers are device pointers.
+struct ProductPools {            // src/cfmms.jl:101-111
+    const double2* R;            // [m] {R1, R2}
+    const double* gamma;         // [m]
+    const int2* Ai;              // [m] {i1, i2}, 0-based
+};
+struct GeoMeanPools {            // src/cfmms.jl:152-165
+    const double2* R;
+    const double2* w;            // [m] {w1, w2}
+    const double* gamma;
+    const int2* Ai;
+};
+struct UniV3Pools {              // src/cfmms.jl:226-245, ticks in CSR form
+    const double2* pg;           // [m] {current_price, gamma}
+    const int2* Ai;              // [m]
+    const int2* span;            // [m] {tick_begin, n_ticks}
+    const int* cur_tick;         // [m] 1-based current_tick (src/cfmms.jl:235)
+    const double2* ticks;        // [T] {lower_tick, liquidity}
+};
+
+struct SweepArgs {
+    const double* v;             // [n] device
+    int n;                       // n_tokens
+    int n_pad;                   // n rounded up to even (LDS row pitch)
+    int copies;                  // private bin copies per block (1 or kWavesPerBlock)
+    int64_t m;                   // pools in this segment
+    double2* Delta;              // [m] segment base, may be null when !materialize
+    double2* Lambda;
+    double* partials;            // [grid][n+1] rows of this segment
+    int nt_stores;               // use non-temporal stores for Delta/Lambda
+};
+
+struct LaunchCfg {
+    int grid;
+    int unroll;                  // 1, 2 or 4 pools per lane per tile
+    size_t lds_bytes;
+};
+
+hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
+                        hipStream_t s);
+hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
+                        hipStream_t s);
+hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
+                        hipStream_t s);
+
+// out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s);
+
+size_t sweep_lds_bytes(int n_pad, int copies);
+hipError_t prepare_kernels(size_t max_lds_bytes);
+
+} // namespace cfmm

@@ -1,0 +1,371 @@
+// sweep_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the per-CFMM arbitrage
+// sweep of CFMMRouter.jl and the reductions route! consumes.
+//
+// What is replaced (paths relative to the reference root):
+//   find_arb!(r::Router, v)            src/router.jl:38-42    -> sweep_kernel<...>
+//   find_arb!(.., ::ProductTwoCoin)    src/cfmms.jl:125-140   -> ProductPools::solve
+//   find_arb!(.., ::GeometricMeanTwoCoin) src/cfmms.jl:180-196 -> GeoMeanPools::solve
+//   find_arb!(.., ::UniV3) + helpers   src/cfmms.jl:294-395   -> UniV3Pools::solve
+//   acc loop of fn                     src/router.jl:79-83    -> per-lane acc + wave shuffles
+//   scatter loop of g! / netflows!     src/router.jl:98-100, :111-119 -> LDS bins + reduce_partials
+//
+// Mapping to the machine.  A two-coin closed form is ~25 dependent flops with no parallelism
+// inside a pool, so the unit of work is ONE LANE PER POOL (64 pools per wavefront); the
+// data-parallel axis is the pool index, exactly the axis the reference threads over.  Pool
+// state is stored as three coalesced streams (reserve pairs 16 B, fee 8 B, token-index pair
+// 8 B per lane) and trades leave as two 16 B/lane streams.  Each wavefront owns a private
+// copy of the n_tokens netflow bins in LDS and scatters (Lambda - Delta) into it with
+// ds_add_f64; the block then folds its copies in a fixed order and writes one partial row to
+// global memory.  A second tiny kernel folds the rows, again in a fixed order, so a sweep
+// is reproducible bit-for-bit for a fixed launch geometry -- there is no global float atomic.
+// The dual scalar is accumulated per lane in tile order and folded with wave shuffles.
+//
+// Numerics.  Everything is binary64.  This translation unit is compiled with
+// -ffp-contract=off and the expressions keep the reference's operation order; with IEEE
+// correctly-rounded / and sqrt the ProductTwoCoin and UniV3 trades are bit-identical to the
+// reference arithmetic.  pow() is the device library's, so GeometricMeanTwoCoin agrees to
+// a few ulp.  HBM-bound by design: no MFMA (there is no contraction anywhere on this path).
+
+#include "sweep.h"
+
+namespace cfmm {
+
+struct Trade {
+    double d1, d2, l1, l2;
+};
+
+// Julia's max(x, 0.0): NaN propagates, max(-0.0, 0.0) == +0.0.
+__device__ __forceinline__ double max0(double x)
+{
+    double r = x > 0.0 ? x : 0.0;
+    return (x != x) ? x : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProductTwoCoin -- src/cfmms.jl:125-140
+// ---------------------------------------------------------------------------------------------
+struct ProductOps {
+    struct Raw {
+        double2 R;
+        double g;
+        int2 ai;
+    };
+    ProductPools p;
+    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.gamma[i], p.Ai[i]}; }
+    __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
+        const double k = R1 * R2;          // :132
+        const double m12 = v2 / v1;        // m of :134/:138
+        const double m21 = v1 / v2;        // m of :135/:137
+        const double gm12 = g * m12;       // γ*m (== m*γ bitwise)
+        const double gm21 = g * m21;
+        t.d1 = max0(sqrt(gm12 * k) - R1) / g;   // :125,:134
+        t.d2 = max0(sqrt(gm21 * k) - R2) / g;   // :125,:135
+        t.l1 = max0(R1 - sqrt(k / gm21));       // :126,:137
+        t.l2 = max0(R2 - sqrt(k / gm12));       // :126,:138
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// GeometricMeanTwoCoin -- src/cfmms.jl:180-196
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double geom_arb_delta(double m, double r1, double r2, double eta, double g)
+{
+    const double inner = (((g * m) * eta) * r1) * pow(r2, eta);    // :180
+    return max0(pow(inner, 1.0 / (eta + 1.0)) - r2) / g;
+}
+__device__ __forceinline__ double geom_arb_lambda(double m, double r1, double r2, double eta, double g)
+{
+    const double base = (r2 * pow(r1, 1.0 / eta)) / ((eta * g) * m); // :181
+    return max0(r1 - pow(base, eta / (1.0 + eta)));
+}
+
+struct GeoMeanOps {
+    struct Raw {
+        double2 R, w;
+        double g;
+        int2 ai;
+    };
+    GeoMeanPools p;
+    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i]}; }
+    __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
+        const double eta = r.w.x / r.w.y;        // :188
+        const double ieta = 1.0 / eta;
+        const double m12 = v2 / v1, m21 = v1 / v2;
+        t.d1 = geom_arb_delta(m12, R2, R1, eta, g);   // :190
+        t.d2 = geom_arb_delta(m21, R1, R2, ieta, g);  // :191
+        t.l1 = geom_arb_lambda(m21, R1, R2, ieta, g); // :193
+        t.l2 = geom_arb_lambda(m12, R2, R1, eta, g);  // :194
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// UniV3 / BoundedProduct -- src/cfmms.jl:294-395 (lane per pool, serial tick walk)
+// ---------------------------------------------------------------------------------------------
+// find_arb_pos(t, price) -- src/cfmms.jl:321-337, on BoundedProduct(k, a, b, R1, R2)
+__device__ __forceinline__ void find_arb_pos(double k, double a, double b, double R1, double R2,
+                                             double price, double& d, double& l)
+{
+    const double s = R1 + a;
+    const double dd = sqrt(k / price) - s;     // :323
+    if (dd <= 0) { d = 0.0; l = 0.0; return; } // :325-327
+    const double dmax = k / b - s;             // :329 (b == 0 -> Inf)
+    if (dd >= dmax) { d = dmax; l = R2; return; } // :330-332
+    l = (R2 + b) - sqrt(price * k);            // :334
+    d = dd;
+}
+
+struct UniV3Ops {
+    struct Raw {
+        double2 pg;
+        int2 ai;
+        int2 span;
+        int ct;
+    };
+    UniV3Pools p;
+    __device__ __forceinline__ Raw load(int64_t i) const
+    {
+        return Raw{p.pg[i], p.Ai[i], p.span[i], p.cur_tick[i]};
+    }
+    __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
+
+    // compute_at_tick(cfmm, idx) -- src/cfmms.jl:294-313; idx is 1-based within the pool
+    __device__ __forceinline__ void at_tick(const Raw& r, int idx, double& k, double& a, double& b,
+                                            double& R1, double& R2) const
+    {
+        const double2* tk = p.ticks + r.span.x;
+        const double2 cur = tk[idx - 1];
+        k = cur.y;
+        const double pplus = cur.x;                                    // :251
+        const double pminus = idx < r.span.y ? tk[idx].x : 0.0;        // :254-259
+        a = sqrt(k / pplus);
+        b = sqrt(k * pminus);
+        const double pp = idx > r.ct ? pplus : (idx < r.ct ? pminus : r.pg.x);
+        R1 = sqrt(k / pp) - a;
+        R2 = sqrt(k * pp) - b;
+    }
+
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double cp = r.pg.x, g = r.pg.y;
+        const double pr = v1 / v2;                                     // :340
+        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
+        double sd = 0.0, sl = 0.0;
+        bool initial = true;
+        if (pr < g * cp) {                                             // :351
+            const double price = pr / g;
+            for (int idx = r.ct; idx <= r.span.y; ++idx) {             // :316
+                double k, a, b, R1, R2;
+                at_tick(r, idx, k, a, b, R1, R2);
+                if (k == 0) { initial = false; continue; }             // :355-358
+                double d, l;
+                find_arb_pos(k, a, b, R1, R2, price, d, l);            // :361
+                if (!initial && (d == 0 || l == 0)) break;             // :363-365
+                sd += d;
+                sl += l;
+                initial = false;
+            }
+            t.d1 = sd / g;                                             // :372
+            t.l2 = sl;
+        } else {
+            const double price = 1.0 / (g * pr);                       // :381
+            for (int idx = r.ct; idx >= 1; --idx) {                    // :317
+                double k, a, b, R1, R2;
+                at_tick(r, idx, k, a, b, R1, R2);
+                if (k == 0) { initial = false; continue; }
+                double d, l;
+                find_arb_pos(k, b, a, R2, R1, price, d, l);            // flip_sides :289
+                if (!initial && (d == 0 || l == 0)) break;
+                sd += d;
+                sl += l;
+                initial = false;
+            }
+            t.d2 = sd / g;                                             // :391
+            t.l1 = sl;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The sweep: src/router.jl:38-42 fused with :79-83 and :98-100
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_pair(double2* dst, double x, double y, int nt)
+{
+    if (nt) {
+        __builtin_nontemporal_store(x, &dst->x);
+        __builtin_nontemporal_store(y, &dst->y);
+    } else {
+        *dst = make_double2(x, y);
+    }
+}
+
+template <class Ops, bool MAT, int U>
+__global__ __launch_bounds__(kBlock) void sweep_kernel(Ops ops, SweepArgs a)
+{
+    extern __shared__ double lds[];
+    double* v_s = lds;                         // [n_pad]
+    double* bins = lds + a.n_pad;              // [copies][n_pad]
+    double* wsum = bins + (size_t)a.copies * a.n_pad; // [kWavesPerBlock]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+
+    for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
+    for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
+    __syncthreads();
+
+    double* my_bins = bins + (size_t)(a.copies == 1 ? 0 : wave) * a.n_pad;
+    double acc = 0.0;
+
+    const int64_t tile_pools = (int64_t)kBlock * U;
+    const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * tile_pools + tid;
+        typename Ops::Raw raw[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * kBlock;
+            ok[u] = i < a.m;
+            if (ok[u]) raw[u] = ops.load(i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int64_t i = base + (int64_t)u * kBlock;
+            const int2 tok = ops.tokens(raw[u]);
+            const double v1 = v_s[tok.x], v2 = v_s[tok.y];   // v[r.cfmms[i].Ai]
+            Trade t;
+            ops.solve(raw[u], v1, v2, t);
+            if (MAT) {
+                store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
+                store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
+            }
+            // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
+            acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
+            // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
+            const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
+            if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
+            if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+        }
+    }
+
+    // fold the dual scalar: lanes by wave shuffles, waves through LDS, fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) wsum[wave] = acc;
+    __syncthreads();
+
+    double* row = a.partials + (size_t)blockIdx.x * (a.n + 1);
+    for (int j = tid; j < a.n; j += kBlock) {
+        double s = bins[j];
+        for (int c = 1; c < a.copies; ++c) s += bins[(size_t)c * a.n_pad + j];
+        row[j] = s;
+    }
+    if (tid == 0) {
+        double s = wsum[0];
+        for (int w = 1; w < kWavesPerBlock; ++w) s += wsum[w];
+        row[a.n] = s;
+    }
+}
+
+// Folds the per-block partial rows: out[j] = sum_rows partials[row][j].  One block owns
+// kReduceCols adjacent columns; its 256 lanes are 16 row-lanes x 16 columns.  Each lane sums
+// its rows in increasing order, the 16 row-lanes are then folded in increasing order.
+__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int rows,
+                                                         int n1, double* __restrict__ out)
+{
+    __shared__ double red[kBlock / kReduceCols][kReduceCols + 1];
+    const int c = threadIdx.x % kReduceCols;
+    const int r = threadIdx.x / kReduceCols;
+    const int col = blockIdx.x * kReduceCols + c;
+    constexpr int kRowLanes = kBlock / kReduceCols;
+    double s = 0.0;
+    if (col < n1) {
+        for (int row = r; row < rows; row += kRowLanes) s += partials[(size_t)row * n1 + col];
+    }
+    red[r][c] = s;
+    __syncthreads();
+    if (r == 0 && col < n1) {
+        double tsum = red[0][c];
+        for (int k = 1; k < kRowLanes; ++k) tsum += red[k][c];
+        out[col] = tsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+size_t sweep_lds_bytes(int n_pad, int copies)
+{
+    return ((size_t)n_pad * (1 + copies) + kWavesPerBlock) * sizeof(double);
+}
+
+template <class Ops>
+static hipError_t set_lds_attr(size_t bytes)
+{
+    hipError_t e;
+#define CFMM_SET(MAT, U)                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, U>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                  \
+    if (e != hipSuccess) return e;
+    CFMM_SET(true, 1) CFMM_SET(true, 2) CFMM_SET(true, 4)
+    CFMM_SET(false, 1) CFMM_SET(false, 2) CFMM_SET(false, 4)
+#undef CFMM_SET
+    return hipSuccess;
+}
+
+hipError_t prepare_kernels(size_t max_lds_bytes)
+{
+    hipError_t e = set_lds_attr<ProductOps>(max_lds_bytes);
+    if (e != hipSuccess) return e;
+    e = set_lds_attr<GeoMeanOps>(max_lds_bytes);
+    if (e != hipSuccess) return e;
+    return set_lds_attr<UniV3Ops>(max_lds_bytes);
+}
+
+template <class Ops>
+static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    if (a.m <= 0) return hipSuccess;
+    dim3 g(c.grid), b(kBlock);
+#define CFMM_GO(MAT, U) hipLaunchKernelGGL((sweep_kernel<Ops, MAT, U>), g, b, c.lds_bytes, s, ops, a)
+    if (mat) {
+        if (c.unroll == 4) CFMM_GO(true, 4);
+        else if (c.unroll == 2) CFMM_GO(true, 2);
+        else CFMM_GO(true, 1);
+    } else {
+        if (c.unroll == 4) CFMM_GO(false, 4);
+        else if (c.unroll == 2) CFMM_GO(false, 2);
+        else CFMM_GO(false, 1);
+    }
+#undef CFMM_GO
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    return launch_any(ProductOps{p}, a, c, mat, s);
+}
+hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    return launch_any(GeoMeanOps{p}, a, c, mat, s);
+}
+hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    return launch_any(UniV3Ops{p}, a, c, mat, s);
+}
+
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s)
+{
+    dim3 g((n1 + kReduceCols - 1) / kReduceCols), b(kBlock);
+    hipLaunchKernelGGL(reduce_partials, g, b, 0, s, partials, rows, n1, out);
+    return hipGetLastError();
+}
+
+} // namespace cfmm

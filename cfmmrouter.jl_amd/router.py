@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's Router / route! (src/router.jl).
+
+    Router(objective, cfmms, n_tokens)      src/router.jl:4-36
+    find_arb_(r, v)   (Julia find_arb!)     src/router.jl:38-42   -> one device sweep
+    route_(r; ...)    (Julia route!)        src/router.jl:58-108
+    netflows_(ψ, r), netflows(r)            src/router.jl:111-125
+    update_reserves_(r)                     src/router.jl:127-132 (unimplemented upstream)
+
+Julia's `!` cannot appear in a Python identifier; mutating verbs carry a trailing underscore.
+`r.Δs` / `r.Λs` / `r.v` / `r.cfmms` / `r.objective` are the reference's fields.
+
+What runs where: pools are packed once into the device pool store (type-partitioned segments,
+SoA-of-pairs); every evaluation of the dual function is ONE call through the C ABI which sweeps
+all pools on the GPU and returns Ψ (n_tokens doubles) and the dual scalar.  The outer L-BFGS-B
+iteration stays on the host, as in the reference (LBFGSB.jl there, SciPy's translation of the same
+L-BFGS-B 3.0 here); its cost is O(n_tokens) per step.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import objectives as _obj
+from ._lib import KIND_GEOMEAN, KIND_PRODUCT, KIND_UNIV3, ArgumentError, Context
+from .cfmms import CFMM, PoolBatch, _upload
+
+
+class DeviceBackend:
+    """The pool store + sweeps of one GPU, behind the C ABI (include/cfmm_amd.h)."""
+
+    def __init__(self, n_tokens, batches, device=0):
+        self.ctx = Context(n_tokens, device)
+        self.n_tokens = int(n_tokens)
+        for b in batches:
+            if len(b):
+                _upload(self.ctx, b)
+
+    def eval(self, v):
+        """fn/g! evaluation without trade write-back -> (Ψ, acc)."""
+        return self.ctx.eval(v)
+
+    def find_arb(self, v):
+        """find_arb!(r, v): trades materialised on the device -> (Ψ, acc)."""
+        self.ctx.find_arb(v)
+        return self.ctx.netflows(), self.ctx.dual_value()
+
+    def trades(self):
+        return self.ctx.trades()
+
+    def close(self):
+        self.ctx.close()
+
+
+def _segments_of(cfmms):
+    """Pack a pool container into homogeneous batches.
+
+    Returns (batches, order) where `order[k]` is the router index of the k-th packed pool
+    (None when packing preserved the router order)."""
+    if isinstance(cfmms, PoolBatch):
+        return [cfmms], None
+    cfmms = list(cfmms)
+    if cfmms and all(isinstance(c, PoolBatch) for c in cfmms):
+        return cfmms, None
+    for c in cfmms:
+        if not isinstance(c, CFMM):
+            raise ArgumentError("cfmms must hold CFMM objects or PoolBatch containers")
+    batches, order = [], []
+    for kind in (KIND_PRODUCT, KIND_GEOMEAN, KIND_UNIV3):
+        idx = [i for i, c in enumerate(cfmms) if c.kind == kind]
+        if idx:
+            batches.append(PoolBatch.from_pools(kind, [cfmms[i] for i in idx]))
+            order.extend(idx)
+    order = np.array(order, dtype=np.int64)
+    if np.array_equal(order, np.arange(len(cfmms))):
+        order = None
+    return batches, order
+
+
+class _PoolView:
+    """`r.cfmms` for batch-built routers: indexable / iterable pool objects, built on demand."""
+
+    def __init__(self, batches):
+        self._batches = batches
+        self._offsets = np.cumsum([0] + [len(b) for b in batches])
+
+    def __len__(self):
+        return int(self._offsets[-1])
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        s = int(np.searchsorted(self._offsets, i, side="right") - 1)
+        return self._batches[s][i - int(self._offsets[s])]
+
+    def __iter__(self):
+        for b in self._batches:
+            for i in range(len(b)):
+                yield b[i]
+
+
+class Router:
+    """Router(objective, cfmms, n_tokens) -- src/router.jl:4-36."""
+
+    def __init__(self, objective, cfmms, n_tokens, device=0, _backend=None):
+        if not isinstance(objective, _obj.Objective):
+            raise ArgumentError("objective must be an Objective")
+        self.objective = objective
+        self.n_tokens = int(n_tokens)
+        if not isinstance(cfmms, PoolBatch):
+            cfmms = list(cfmms)
+        batches, self._order = _segments_of(cfmms)
+        self._batches = batches
+        from_batches = isinstance(cfmms, PoolBatch) or (
+            len(batches) > 0 and not isinstance(cfmms, PoolBatch) and all(isinstance(c, PoolBatch) for c in cfmms))
+        self.cfmms = _PoolView(batches) if from_batches else list(cfmms)
+        self._m = sum(len(b) for b in batches)
+        self.v = np.zeros(self.n_tokens)  # :33
+        self._backend = _backend if _backend is not None else DeviceBackend(self.n_tokens, batches, device)
+        self._psi = np.zeros(self.n_tokens)
+        self._acc = 0.0
+        self._Δs = np.zeros((self._m, 2))  # zerotrade per pool, :23-26
+        self._Λs = np.zeros((self._m, 2))
+        self._trades_stale = False
+        self.n_sweeps = 0
+        self.info = None
+
+    # r.Δs / r.Λs: [m, 2] arrays in router order (rows are the reference's per-pool vectors)
+    def _fetch(self):
+        if self._trades_stale:
+            D, Lm = self._backend.trades()
+            if self._order is not None:
+                self._Δs[self._order] = D
+                self._Λs[self._order] = Lm
+            else:
+                self._Δs, self._Λs = D, Lm
+            self._trades_stale = False
+
+    @property
+    def Δs(self):
+        self._fetch()
+        return self._Δs
+
+    @property
+    def Λs(self):
+        self._fetch()
+        return self._Λs
+
+    Deltas = Δs
+    Lambdas = Λs
+
+    def close(self):
+        if hasattr(self._backend, "close"):
+            self._backend.close()
+
+
+def find_arb_(r: Router, v):
+    """find_arb!(r::Router, v) -- src/router.jl:38-42: every pool's arbitrage at prices v."""
+    v = np.asarray(v, dtype=np.float64)
+    r._psi, r._acc = r._backend.find_arb(v)
+    r._trades_stale = True
+    r.n_sweeps += 1
+    return None
+
+
+def route_(r: Router, v=None, verbose=False, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000):
+    """route!(r; v, verbose, m, factr, pgtol, maxfun, maxiter) -- src/router.jl:58-108.
+
+    Overwrites r.Δs, r.Λs and r.v.  The dual function g(ν) = f(ν) + Σᵢ arbᵢ(Aᵢᵀν) is minimised
+    with L-BFGS-B over the objective's box; each evaluation is one device sweep."""
+    from scipy.optimize import fmin_l_bfgs_b
+
+    n = r.v.size
+    if v is None:
+        r.v[:] = np.ones(n) / n  # :62
+    else:
+        r.v[:] = v  # :64
+    lo = _obj.lower_limit(r.objective)  # :67-70 (nbd = 2 with an infinite upper bound)
+    up = _obj.upper_limit(r.objective)
+    bounds = [(lo[j], None if math.isinf(up[j]) else up[j]) for j in range(n)]
+
+    def sweep(x):
+        r._psi, r._acc = r._backend.eval(x)
+        r.n_sweeps += 1
+
+    def fg(x):
+        if not np.all(x == r.v):  # :74-77 / :92-95: one sweep per evaluation
+            sweep(x)
+            r.v[:] = x
+        fval = _obj.f(r.objective, x) + r._acc  # :79-85
+        G = np.zeros(n)  # :90
+        _obj.grad_(G, r.objective, x)  # :96
+        G += r._psi  # :98-100
+        return fval, G
+
+    sweep(r.v)  # :104
+    kw = dict(bounds=bounds, m=m, factr=factr, pgtol=pgtol, maxfun=maxfun, maxiter=maxiter)
+    if verbose:
+        kw["iprint"] = 1
+    x, fmin, info = fmin_l_bfgs_b(fg, r.v.copy(), **kw)  # :105
+    r.v[:] = x  # :106
+    r.info = {"f": fmin, **{k: info[k] for k in ("warnflag", "task", "funcalls", "nit") if k in info}}
+    find_arb_(r, r.v)  # :107
+    return None
+
+
+def netflows_(ψ, r: Router):
+    """netflows!(ψ, r) -- src/router.jl:111-119: ψ = Σᵢ Aᵢ(Λᵢ − Δᵢ) for the latest sweep."""
+    ψ[:] = r._psi
+    return None
+
+
+def netflows(r: Router):
+    """netflows(r) -- src/router.jl:121-125"""
+    ψ = np.zeros_like(r.v)
+    netflows_(ψ, r)
+    return ψ
+
+
+def update_reserves_(r: Router):
+    """update_reserves!(r) -- src/router.jl:127-132.  The reference calls a per-CFMM method that
+    is defined nowhere (its own test marks it "borked", test/arb.jl:30-39); same here."""
+    raise NotImplementedError("update_reserves! has no per-CFMM method in the reference (MethodError there)")

@@ -1,0 +1,141 @@
+/*
+ * cfmm_amd.h -- C ABI of libcfmm_amd.so: the MI355X (gfx950) implementation of
+ * CFMMRouter.jl's per-CFMM arbitrage sweep and the reductions route! consumes.
+ *
+ * The reference has no FFI seam (it is one Julia module); this header IS the seam a
+ * maintainer binds with `ccall` (julia/CFMMRouterAMD.jl).  Each entry
+ * point names the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns CFMM_OK (0) or a negative error code;
+ *     cfmm_last_error() returns the message.  (Reference: ArgumentError from the
+ *     constructors src/cfmms.jl:77-78, src/objectives.jl:54,97 -- nothing else.)
+ *   - all values are IEEE binary64, computed in binary64 on the device.
+ *   - token indices are 0-based int32 on this side (reference: 1-based Int64,
+ *     src/cfmms.jl:10,16); the binding subtracts 1 when packing.
+ *   - "pair" arrays are [m][2] row-major: R = {R1,R2}, Ai = {i1,i2}, w = {w1,w2},
+ *     Delta = {D1,D2}, Lambda = {L1,L2} -- the reference's per-pool 2-vectors, contiguous.
+ *   - host pointers are only read/written during the call; the library copies.
+ *   - a cfmm_ctx is bound to one device and is not re-entrant; distinct contexts are
+ *     independent.  Host-pointer calls are synchronous; *_dev calls are asynchronous on
+ *     the context's stream.
+ *   - pools are stored in SEGMENTS (one per cfmm_pools_add_* call, each homogeneous in
+ *     pool family).  Trade arrays are laid out segment after segment in call order, so a
+ *     router whose cfmms vector is grouped by family keeps the reference's pool order.
+ */
+#ifndef CFMM_AMD_H
+#define CFMM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFMM_OK 0
+#define CFMM_ERR_INVALID_ARG (-1) /* bad pointer / size / pool data (the reference's ArgumentError) */
+#define CFMM_ERR_HIP (-2)         /* a HIP runtime call failed; message carries hipGetErrorString */
+#define CFMM_ERR_STATE (-3)       /* call sequence error (e.g. netflows before any sweep) */
+#define CFMM_ERR_UNSUPPORTED (-4) /* valid request outside the implemented envelope */
+
+#define CFMM_KIND_PRODUCT 0 /* ProductTwoCoin        src/cfmms.jl:101-140 */
+#define CFMM_KIND_GEOMEAN 1 /* GeometricMeanTwoCoin  src/cfmms.jl:152-196 */
+#define CFMM_KIND_UNIV3 2   /* UniV3/BoundedProduct  src/cfmms.jl:226-395 */
+
+typedef struct cfmm_ctx cfmm_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Router(objective, cfmms, n_tokens) -- src/router.jl:18-36: the device-side half of the
+ * Router (pool store, trade buffers, v).  device_id is a HIP ordinal. */
+int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out);
+void cfmm_ctx_destroy(cfmm_ctx* ctx);
+
+/* Message of the last failing call on ctx (ctx == NULL: last failing cfmm_ctx_create on
+ * this thread).  Never NULL; valid until the next call on the same ctx/thread. */
+const char* cfmm_last_error(const cfmm_ctx* ctx);
+const char* cfmm_version(void);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own stream.  NULL restores the context's stream. */
+int cfmm_set_stream(cfmm_ctx* ctx, void* hip_stream);
+
+/* Tuning / instrumentation knobs: "max_grid", "unroll", "bin_copies", "time_kernels",
+ * "nt_stores".  Unknown keys are CFMM_ERR_INVALID_ARG. */
+int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);
+int cfmm_get_option(const cfmm_ctx* ctx, const char* key, int64_t* value);
+
+/* ---- pool upload (struct definitions + constructors, packed once) --------------------- */
+
+/* m x ProductTwoCoin(R, gamma, idx) -- src/cfmms.jl:101-111 (+ checks of :76-90).
+ * R[m][2] > 0, gamma[m] > 0, Ai[m][2] distinct and in [0, n_tokens). */
+int cfmm_pools_add_product(cfmm_ctx* ctx, int64_t m, const double* R, const double* gamma,
+                           const int32_t* Ai);
+
+/* m x GeometricMeanTwoCoin(R, w, gamma, idx) -- src/cfmms.jl:152-165.  w[m][2] > 0. */
+int cfmm_pools_add_geomean(cfmm_ctx* ctx, int64_t m, const double* R, const double* w,
+                           const double* gamma, const int32_t* Ai);
+
+/* m x UniV3(current_price, lower_ticks, liquidity, gamma, Ai) -- src/cfmms.jl:226-245,
+ * ragged ticks in CSR form: pool i owns lower_ticks/liquidity[tick_off[i] .. tick_off[i+1]).
+ * lower_ticks strictly descending and > 0 per pool, liquidity >= 0, and
+ * current_price <= lower_ticks[first] (the reference would index tick 0 otherwise, :235,:316).
+ * current_tick is derived here exactly as :235 does.  A stand-alone BoundedProduct pool
+ * (src/cfmms.jl:272-289) is a UniV3 with two ticks whose second liquidity is 0. */
+int cfmm_pools_add_univ3(cfmm_ctx* ctx, int64_t m, const double* current_price, const double* gamma,
+                         const int32_t* Ai, const int64_t* tick_off, const double* lower_ticks,
+                         const double* liquidity);
+
+int cfmm_pools_clear(cfmm_ctx* ctx);
+int64_t cfmm_pools_count(const cfmm_ctx* ctx); /* length(r.cfmms) */
+int32_t cfmm_n_tokens(const cfmm_ctx* ctx);    /* length(r.v) */
+
+/* ---- the hot path --------------------------------------------------------------------- */
+
+/* find_arb!(r::Router, v) -- src/router.jl:38-42, dispatching to src/cfmms.jl:130-140,
+ * :185-196, :339-395 per segment.  Materialising sweep: writes every pool's Delta/Lambda
+ * to device memory AND reduces psi = sum_i A_i(Lambda_i - Delta_i) and the dual scalar
+ * acc = sum_i (Lambda_i - Delta_i)'v[A_i] in the same pass.  v: n_tokens host doubles. */
+int cfmm_find_arb(cfmm_ctx* ctx, const double* v);
+
+/* The evaluation route!'s closures fn / g! need (src/router.jl:73-86, :89-102) without the
+ * O(m) trade write-back: psi_out[n_tokens] = pool part of G (== netflows at v),
+ * *acc_out = pool part of fn.  Either output pointer may be NULL. */
+int cfmm_eval(cfmm_ctx* ctx, const double* v, double* psi_out, double* acc_out);
+
+/* r.Δs / r.Λs after find_arb! -- src/router.jl:7-8,40.  [m_total][2] each, segment order.
+ * Requires a preceding cfmm_find_arb (cfmm_eval does not produce trades). */
+int cfmm_get_trades(cfmm_ctx* ctx, double* Delta, double* Lambda);
+/* Same, one segment: rows [first, first+count) of segment `seg`. */
+int cfmm_get_trades_range(cfmm_ctx* ctx, int32_t seg, int64_t first, int64_t count, double* Delta,
+                          double* Lambda);
+
+/* netflows!(psi, r) -- src/router.jl:111-119, for the most recent sweep. */
+int cfmm_netflows(cfmm_ctx* ctx, double* psi);
+/* the `acc` of fn (src/router.jl:79-83) for the most recent sweep. */
+int cfmm_dual_value(cfmm_ctx* ctx, double* acc);
+
+/* ---- device-resident variants (stream / RCCL interop; no host round trip) -------------- */
+
+/* d_v: n_tokens device doubles.  d_out: n_tokens+1 device doubles = {psi..., acc}: the
+ * buffer a sharded run all-reduces (one collective per evaluation).  Asynchronous on the
+ * context's stream.  materialize != 0: also write Delta/Lambda (find_arb! semantics). */
+int cfmm_sweep_dev(cfmm_ctx* ctx, const double* d_v, double* d_out, int materialize);
+/* Device addresses of the trade buffers ([m_total][2] doubles each), valid until pools change. */
+int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lambda);
+
+/* With option "time_kernels"=1 every sweep launch is bracketed by hipEvents on the launch
+ * stream.  Returns and resets: number of timed sweep-kernel launches, their summed
+ * duration, and the same for the partial-reduction kernel. */
+int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
+                      int64_t* reduce_launches, double* reduce_ms);
+
+/* Number of segments and their description (kind, pool count, grid, unroll). */
+int32_t cfmm_segment_count(const cfmm_ctx* ctx);
+int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* grid,
+                      int32_t* unroll);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

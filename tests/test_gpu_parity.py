@@ -1,0 +1,271 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): netflows within 1e-6 relative.  What is actually asserted is far
+tighter and stated per test: ProductTwoCoin / UniV3 trades BIT-EXACT (IEEE sqrt and / on both
+sides, same operation order), GeometricMeanTwoCoin within a few ulp (different pow
+implementations), reductions within 1e-12 of max|Ψ| (different summation order).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from oracle import cfmm_oracle as orc
+from helpers import oracle_objective, oracle_poolset, oracle_sweep, rel_to_max
+
+pytestmark = pytest.mark.gpu
+
+REDUCE_TOL = 1e-12   # of max|Ψ|: fp64 sums in a different order
+GEOM_RTOL = 1e-12    # per trade, relative to the reserve scale
+ROUTE_TOL = 1e-6     # north_star tolerance on route!-level netflows, relative to max|Ψ|
+
+
+def device_sweep(batches, n, v, materialize=True, **opts):
+    be = cr.DeviceBackend(n, batches)
+    for k, val in opts.items():
+        be.ctx.set_option(k, val)
+    try:
+        if materialize:
+            psi, acc = be.find_arb(v)
+            D, L = be.trades()
+        else:
+            psi, acc = be.eval(v)
+            D = L = None
+        return D, L, psi, acc
+    finally:
+        be.close()
+
+
+# ---- reference KATs straight through the device (test/cfmms.jl:70-90) ---------------------------
+
+class TestProductKAT:
+    def test_no_arb_and_easy_arb(self):
+        Δ, Λ = np.empty(2), np.empty(2)
+        equal_pool = cr.ProductTwoCoin([1, 1], 1, [1, 2])
+        for v in ([1.0, 1.0], [2.0, 2.0]):
+            cr.find_arb_(Δ, Λ, equal_pool, v)
+            assert np.all(Δ == 0) and np.all(Λ == 0)
+        cr.find_arb_(Δ, Λ, equal_pool, [2.0, 1.0])
+        assert Δ[0] == 0 and Δ[1] == math.sqrt(2) - 1
+        assert Λ[0] == 1 - math.sqrt(1 / 2) and Λ[1] == 0
+
+    def test_ctor_errors(self):
+        assert len(cr.ProductTwoCoin([1, 1], .9, [1, 2])) == 2
+        with pytest.raises(cr.ArgumentError):
+            cr.ProductTwoCoin([1, 1], .9, [1])
+
+
+class TestUniV3KAT:
+    """test/cfmms.jl:112-203 on the device; the oracle already satisfies the reference's predicates
+    (tests/test_oracle_kat.py), so bit-equality with it carries them over."""
+
+    @pytest.mark.parametrize("γ", [1.0, 0.997])
+    @pytest.mark.parametrize("p", [15.0, 15.0 * (1 + 0.997) / 2, 16.0, 14.0, 25.0, 7.5, 4.0, 35.0])
+    def test_fixture(self, γ, p):
+        cfmm = cr.UniV3(15.0, [30., 20, 10, 5], [1.0, 2.0, 1.5, 0.0], γ, [1, 2])
+        assert cfmm.current_tick == 2
+        Δ, Λ = np.zeros(2), np.zeros(2)
+        cr.find_arb_(Δ, Λ, cfmm, [p, 1.0])
+        D, L = orc.UniV3(15.0, [30., 20, 10, 5], [1.0, 2.0, 1.5, 0.0], γ).find_arb([p, 1.0])
+        np.testing.assert_array_equal(Δ, D)
+        np.testing.assert_array_equal(Λ, L)
+
+
+# ---- fixed-v sweeps ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("m,n", [(1, 2), (255, 7), (256, 64), (257, 64), (1000, 3), (100_000, 64), (300_001, 257)])
+def test_product_sweep_bit_exact(m, n):
+    b = synth.product_pools(m, n, seed=m + n)
+    v = synth.sweep_prices(n, seed=m)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psio) <= REDUCE_TOL
+    assert abs(acc - acco) <= REDUCE_TOL * max(abs(acco), 1.0)
+
+
+@pytest.mark.parametrize("unroll", [1, 2, 4])
+@pytest.mark.parametrize("copies", [1, 4])
+def test_product_launch_variants(unroll, copies):
+    m, n = 70_001, 96
+    b = synth.product_pools(m, n, seed=3)
+    v = synth.sweep_prices(n, seed=4)
+    D, L, psi, acc = device_sweep([b], n, v, unroll=unroll, bin_copies=copies, max_grid=64)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psio) <= REDUCE_TOL
+
+
+@pytest.mark.parametrize("m,n", [(1, 2), (513, 16), (50_000, 256)])
+def test_geomean_sweep(m, n):
+    b = synth.geomean_pools(m, n, seed=m)
+    v = synth.sweep_prices(n, seed=n)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    scale = np.max(b.R, axis=1, keepdims=True)
+    assert np.max(np.abs(D - Do) / scale) <= GEOM_RTOL
+    assert np.max(np.abs(L - Lo) / scale) <= GEOM_RTOL
+    assert rel_to_max(psi, psio) <= 1e-11
+    assert abs(acc - acco) <= 1e-10 * max(abs(acco), 1.0)
+
+
+@pytest.mark.parametrize("m,n,t", [(1, 2, 1), (300, 8, 2), (4097, 64, 5), (20_000, 128, 17)])
+def test_univ3_sweep_bit_exact(m, n, t):
+    b = synth.univ3_pools(m, n, t, seed=m) if t != 2 else synth.bounded_product_pools(m, n, seed=m)
+    v = synth.sweep_prices(n, seed=t, spread=1.0)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert np.count_nonzero(D) > 0
+    assert rel_to_max(psi, psio) <= REDUCE_TOL
+
+
+def test_mixed_segments_and_router_order():
+    """Config-3 shape in miniature + a router whose cfmms vector interleaves the families."""
+    n = 32
+    bp, bg, bu = synth.product_pools(700, n, 1), synth.geomean_pools(300, n, 2), synth.univ3_pools(100, n, 4, 3)
+    v = synth.sweep_prices(n, seed=9, spread=0.5)
+    D, L, psi, acc = device_sweep([bp, bg, bu], n, v)
+    Do, Lo, psio, acco = oracle_sweep([bp, bg, bu], n, v)
+    np.testing.assert_array_equal(D[:700], Do[:700])
+    np.testing.assert_array_equal(D[1000:], Do[1000:])
+    assert np.max(np.abs(D[700:1000] - Do[700:1000])) <= 1e-9
+    assert rel_to_max(psi, psio) <= 1e-11
+    # interleaved object list -> packed by family, results un-permuted to router order
+    pools = []
+    for i in range(100):
+        pools += [bp[i], bg[i], bu[i]]
+    r = cr.Router(cr.LinearNonnegative(np.ones(n)), pools, n)
+    cr.find_arb_(r, v)
+    for i in range(100):
+        np.testing.assert_array_equal(r.Δs[3 * i], Do[i])
+        np.testing.assert_array_equal(r.Δs[3 * i + 2], Do[1000 + i])
+        assert np.max(np.abs(r.Λs[3 * i + 1] - Lo[700 + i])) <= 1e-9
+    r.close()
+
+
+def test_fused_equals_materialised_and_deterministic():
+    m, n = 200_000, 64
+    b = synth.product_pools(m, n, seed=5)
+    v = synth.sweep_prices(n, seed=6)
+    be = cr.DeviceBackend(n, [b])
+    psi1, acc1 = be.find_arb(v)
+    psi2, acc2 = be.eval(v)
+    psi3, acc3 = be.find_arb(v)
+    np.testing.assert_array_equal(psi1, psi2)   # same kernel body, same launch geometry
+    np.testing.assert_array_equal(psi1, psi3)   # no float atomics in global memory: reproducible
+    assert acc1 == acc2 == acc3
+    be.close()
+
+
+def test_empty_router_and_bad_inputs():
+    be = cr.DeviceBackend(4, [])
+    psi, acc = be.find_arb(np.ones(4))
+    assert np.all(psi == 0) and acc == 0
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_product([[1.0, 2.0]], [1.0], [[0, 0]])         # same token twice
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_product([[1.0, 2.0]], [1.0], [[0, 4]])         # index out of range
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_product([[0.0, 2.0]], [1.0], [[0, 1]])         # empty reserve
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_product([[1.0, 2.0]], [0.0], [[0, 1]])         # γ = 0
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_univ3([1.0], [1.0], [[0, 1]], [0, 2], [1.0, 2.0], [1.0, 1.0])  # ascending ticks
+    with pytest.raises(cr.ArgumentError):
+        be.ctx.add_univ3([3.0], [1.0], [[0, 1]], [0, 2], [2.0, 1.0], [1.0, 1.0])  # price above first tick
+    with pytest.raises(cr.ArgumentError):
+        be.find_arb(np.array([1.0, 0.0, 1.0, 1.0]))               # v must be > 0
+    with pytest.raises(RuntimeError):
+        cr.DeviceBackend(4, []).trades()                           # no sweep yet
+    be.close()
+
+
+def test_max_tokens():
+    n = 8192
+    b = synth.product_pools(30_000, n, seed=8)
+    v = synth.sweep_prices(n, seed=8)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    assert rel_to_max(psi, psio) <= REDUCE_TOL
+    with pytest.raises(NotImplementedError):
+        cr.Context(8193)
+
+
+# ---- route! ---------------------------------------------------------------------------------------------
+
+def route_both(objective, batches_or_pools, n, v0=None):
+    r = cr.Router(objective, batches_or_pools, n)
+    cr.route_(r, v=v0)
+    ref = orc.route_oracle(oracle_objective(objective), oracle_poolset(r._batches, n), v0=v0)
+    return r, ref
+
+
+def test_route_readme_example():
+    """README.md:27-38 (config 1)."""
+    pools = [cr.ProductTwoCoin([1e6, 1e6], 1, [1, 2]), cr.ProductTwoCoin([1e3, 2e3], 1, [1, 2])]
+    r, ref = route_both(cr.LinearNonnegative(np.ones(2)), pools, 2)
+    Ψ = cr.netflows(r)
+    assert rel_to_max(Ψ, ref["psi"]) <= ROUTE_TOL
+    assert abs(Ψ[1] - 171.4) < 0.1 and abs(Ψ[0]) < 1e-3     # SURVEY §8c analytic cross-check
+    np.testing.assert_allclose(r.v, ref["v"], rtol=1e-9)
+    r.close()
+
+
+@pytest.mark.parametrize("m,n", [(100, 10), (10_000, 100), (100_000, 64)])
+def test_route_arbitrage_parity(m, n):
+    """test/arb.jl:61-86 shape (m=100) up to config 2 (100k pools, 64 tokens)."""
+    b = synth.product_pools(m, n, seed=1234)
+    obj = cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
+    r, ref = route_both(obj, b, n, v0=np.ones(n))
+    assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
+    assert np.all(cr.netflows(r) >= -1e-4 * max(1.0, np.max(np.abs(ref["psi"])) * 1e-6))
+    assert np.all(r.v >= cr.lower_limit(obj) - 1e-4)
+    r.close()
+
+
+def test_route_basket_liquidation_parity():
+    """test/swap.jl:20-46 shape + examples/liquidate.jl."""
+    n, m = 10, 100
+    b = synth.product_pools(m, n, seed=77)
+    obj = cr.BasketLiquidation(1, synth.basket(n, seed=77))
+    r, ref = route_both(obj, b, n)
+    assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
+    r.close()
+    cfmms = [cr.ProductTwoCoin([1e3, 1e4], 0.997, [1, 2]), cr.ProductTwoCoin([1e3, 1e2], 0.997, [2, 3]),
+             cr.ProductTwoCoin([1e3, 2e4], 0.997, [1, 3])]
+    r, ref = route_both(cr.BasketLiquidation(1, [0, 1e1, 1e2]), cfmms, 3)
+    assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
+    assert cr.netflows(r)[0] > 0
+    r.close()
+
+
+# ---- BASELINE-size properties (no oracle at this size inside the timed budget) ---------------------------
+
+def test_full_size_properties():
+    """1M ProductTwoCoin pools, 256 tokens: size-independent checks."""
+    m, n = 1_000_000, 256
+    b = synth.product_pools(m, n, seed=1234)
+    v = synth.sweep_prices(n, seed=1234)
+    be = cr.DeviceBackend(n, [b])
+    psi, acc = be.find_arb(v)
+    D, L = be.trades()
+    be.close()
+    assert np.all(D >= 0) and np.all(L >= 0)
+    assert not np.any((D[:, 0] > 0) & (D[:, 1] > 0))                  # one direction per pool
+    Rn = b.R + b.γ[:, None] * D - L
+    k0, k1 = b.R[:, 0] * b.R[:, 1], Rn[:, 0] * Rn[:, 1]
+    assert np.all(k1 >= k0 * (1 - 1e-12))                             # trading function not decreased
+    Ai0 = (b.Ai - 1).astype(np.int32)
+    psi_host = orc.netflows(D, L, Ai0, n)                             # checksum of the device's own trades
+    assert rel_to_max(psi, psi_host) <= REDUCE_TOL
+    i = np.arange(0, m, 997)                                          # spot-check rows against the oracle
+    Do, Lo = orc.sweep_product(b.R[i], b.γ[i], Ai0[i], v)
+    np.testing.assert_array_equal(D[i], Do)
+    np.testing.assert_array_equal(L[i], Lo)
