@@ -97,7 +97,7 @@ def lib():
     L.cfmm_kernel_times.argtypes = [_ctx, _i64p, _f64p, _i64p, _f64p]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
-    L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p]
+    L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p, _i32p]
     _lib = L
     return L
 
@@ -264,8 +264,9 @@ class Context:
     def segments(self):
         out = []
         for s in range(self._L.cfmm_segment_count(self._h)):
-            k, g, u = C.c_int32(), C.c_int32(), C.c_int32()
+            k, b, g, u = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
             m = C.c_int64()
-            self._check(self._L.cfmm_segment_info(self._h, s, C.byref(k), C.byref(m), C.byref(g), C.byref(u)))
-            out.append({"kind": k.value, "m": m.value, "grid": g.value, "unroll": u.value})
+            self._check(self._L.cfmm_segment_info(self._h, s, C.byref(k), C.byref(m), C.byref(b), C.byref(g),
+                                                  C.byref(u)))
+            out.append({"kind": k.value, "m": m.value, "block": b.value, "grid": g.value, "unroll": u.value})
         return out

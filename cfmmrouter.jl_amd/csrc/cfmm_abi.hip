@@ -39,6 +39,7 @@ struct Segment {
     int* cur_tick = nullptr;
     double2* ticks = nullptr;
     // launch geometry (decided at upload)
+    int block = kSmallBlock;
     int grid = 0;
     int unroll = 1;
     int64_t row_off = 0; // first partial row
@@ -70,9 +71,10 @@ struct cfmm_ctx {
     bool geometry_dirty = true;
 
     // options
-    int64_t opt_max_grid = 2048;
+    int64_t opt_max_grid = 0;    // 0 = auto (512 fat blocks / 2048 small blocks)
+    int64_t opt_block = 0;       // 0 = auto, else kSmallBlock or kBigBlock
     int64_t opt_unroll = 0;      // 0 = auto
-    int64_t opt_bin_copies = 0;  // 0 = auto
+    int64_t opt_bin_copies = 0;  // 0 = auto, 1 = one shared copy, 2 = one copy per wavefront
     int64_t opt_time_kernels = 0;
     int64_t opt_nt_stores = 0;
 
@@ -147,7 +149,9 @@ int check_two_coin(cfmm_ctx* c, int64_t m, const double* R, const double* gamma,
     return CFMM_OK;
 }
 
-// Launch geometry for a segment of m pools.
+// Launch geometry for a segment of m pools.  Small markets: 256-thread blocks, one tile each
+// (enough blocks to cover 256 CUs).  Large markets: 1024-thread blocks, at most two per CU, each
+// striding over many tiles -- this keeps the number of partial rows (and the fold kernel) small.
 void plan_segment(const cfmm_ctx* c, Segment& s)
 {
     int U = (int)c->opt_unroll;
@@ -155,17 +159,33 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
         if (s.kind == CFMM_KIND_PRODUCT) U = s.m >= (1 << 19) ? 4 : (s.m >= (1 << 18) ? 2 : 1);
         else U = s.m >= (1 << 20) ? 2 : 1; // pow / tick walks carry more live state per pool
     }
-    const int64_t tile = (int64_t)kBlock * U;
-    const int64_t tiles = std::max<int64_t>(1, (s.m + tile - 1) / tile);
     s.unroll = U;
-    s.grid = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, c->opt_max_grid));
+    const int64_t tiles_small = std::max<int64_t>(1, (s.m + (int64_t)kSmallBlock * U - 1) / ((int64_t)kSmallBlock * U));
+    const bool small = c->opt_block == kSmallBlock || (c->opt_block == 0 && tiles_small <= 512);
+    if (small) {
+        s.block = kSmallBlock;
+        s.grid = (int)std::min<int64_t>(tiles_small, c->opt_max_grid > 0 ? c->opt_max_grid : 2048);
+    } else {
+        s.block = kBigBlock;
+        const int64_t tiles = std::max<int64_t>(1, (s.m + (int64_t)kBigBlock * U - 1) / ((int64_t)kBigBlock * U));
+        s.grid = (int)std::min<int64_t>(tiles, c->opt_max_grid > 0 ? c->opt_max_grid : 512);
+    }
 }
 
-int bin_copies(const cfmm_ctx* c)
+int bin_copies(const cfmm_ctx* c, int block)
 {
-    if (c->opt_bin_copies == 1 || c->opt_bin_copies == kWavesPerBlock) return (int)c->opt_bin_copies;
-    // one private copy per wavefront while the block stays under 64 KiB of LDS
-    return sweep_lds_bytes(c->n_pad, kWavesPerBlock) <= 64 * 1024 ? kWavesPerBlock : 1;
+    const int waves = block / 64;
+    if (c->opt_bin_copies == 1) return 1;
+    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block);
+    if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
+    // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
+    return per_wave <= (block == kBigBlock ? 80 : 64) * 1024 ? waves : 1;
+}
+
+size_t max_lds(const cfmm_ctx* c)
+{
+    return std::max(sweep_lds_bytes(c->n_pad, bin_copies(c, kSmallBlock), kSmallBlock),
+                    sweep_lds_bytes(c->n_pad, bin_copies(c, kBigBlock), kBigBlock));
 }
 
 int ensure_geometry(cfmm_ctx* c)
@@ -217,8 +237,6 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
 {
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
-    const int copies = bin_copies(c);
-    const size_t lds = sweep_lds_bytes(c->n_pad, copies);
     const bool timed = c->opt_time_kernels != 0;
     HIP_TRY(c, hipSetDevice(c->device));
     for (auto& s : c->segs) {
@@ -226,13 +244,13 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.v = d_v;
         a.n = c->n;
         a.n_pad = c->n_pad;
-        a.copies = copies;
+        a.copies = bin_copies(c, s.block);
         a.m = s.m;
         a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
         a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
         a.partials = c->d_partials + (size_t)s.row_off * (c->n + 1);
         a.nt_stores = (int)c->opt_nt_stores;
-        LaunchCfg cfg{s.grid, s.unroll, lds};
+        LaunchCfg cfg{s.block, s.grid, s.unroll, sweep_lds_bytes(c->n_pad, a.copies, s.block)};
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) {
             ea = take_event(c);
@@ -352,7 +370,7 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double), hipHostMallocDefault));
-    HIP_TRY_C(prepare_kernels(std::max(sweep_lds_bytes(c->n_pad, 1), sweep_lds_bytes(c->n_pad, bin_copies(c)))));
+    HIP_TRY_C(prepare_kernels(max_lds(c)));
 #undef HIP_TRY_C
     *out = c;
     return CFMM_OK;
@@ -384,6 +402,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!key) return nullptr;
     if (!std::strcmp(key, "max_grid")) return &c->opt_max_grid;
     if (!std::strcmp(key, "unroll")) return &c->opt_unroll;
+    if (!std::strcmp(key, "block")) return &c->opt_block;
     if (!std::strcmp(key, "bin_copies")) return &c->opt_bin_copies;
     if (!std::strcmp(key, "time_kernels")) return &c->opt_time_kernels;
     if (!std::strcmp(key, "nt_stores")) return &c->opt_nt_stores;
@@ -395,20 +414,19 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
     if (!c) return CFMM_ERR_INVALID_ARG;
     int64_t* slot = option_slot(c, key);
     if (!slot) return fail(c, CFMM_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
-    if (slot == &c->opt_max_grid && value < 1) return fail(c, CFMM_ERR_INVALID_ARG, "max_grid must be >= 1");
+    if (slot == &c->opt_max_grid && value < 0) return fail(c, CFMM_ERR_INVALID_ARG, "max_grid must be >= 0 (0 = auto)");
     if (slot == &c->opt_unroll && !(value == 0 || value == 1 || value == 2 || value == 4))
         return fail(c, CFMM_ERR_INVALID_ARG, "unroll must be 0 (auto), 1, 2 or 4");
-    if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == kWavesPerBlock))
-        return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 or %d", kWavesPerBlock);
-    if (slot == &c->opt_bin_copies && value == kWavesPerBlock &&
-        sweep_lds_bytes(c->n_pad, kWavesPerBlock) > 160 * 1024)
-        return fail(c, CFMM_ERR_UNSUPPORTED, "bin_copies=%d does not fit LDS at n_tokens=%d", kWavesPerBlock, c->n);
+    if (slot == &c->opt_block && !(value == 0 || value == kSmallBlock || value == kBigBlock))
+        return fail(c, CFMM_ERR_INVALID_ARG, "block must be 0 (auto), %d or %d", kSmallBlock, kBigBlock);
+    if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == 2))
+        return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 (shared) or 2 (per wavefront)");
     *slot = value;
     if (slot == &c->opt_bin_copies) {
-        hipError_t e = prepare_kernels(std::max(sweep_lds_bytes(c->n_pad, 1), sweep_lds_bytes(c->n_pad, bin_copies(c))));
+        hipError_t e = prepare_kernels(max_lds(c));
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "prepare_kernels: %s", hipGetErrorString(e));
     }
-    if (slot == &c->opt_max_grid || slot == &c->opt_unroll) c->geometry_dirty = true;
+    if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block) c->geometry_dirty = true;
     return CFMM_OK;
 }
 
@@ -651,7 +669,8 @@ int cfmm_kernel_times(cfmm_ctx* c, int64_t* sweep_launches, double* sweep_ms, in
 
 int32_t cfmm_segment_count(const cfmm_ctx* c) { return c ? (int32_t)c->segs.size() : 0; }
 
-int cfmm_segment_info(const cfmm_ctx* c, int32_t seg, int32_t* kind, int64_t* m, int32_t* grid, int32_t* unroll)
+int cfmm_segment_info(const cfmm_ctx* c, int32_t seg, int32_t* kind, int64_t* m, int32_t* block, int32_t* grid,
+                      int32_t* unroll)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
     if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
@@ -660,6 +679,7 @@ int cfmm_segment_info(const cfmm_ctx* c, int32_t seg, int32_t* kind, int64_t* m,
     const Segment& s = c->segs[(size_t)seg];
     if (kind) *kind = s.kind;
     if (m) *m = s.m;
+    if (block) *block = s.block;
     if (grid) *grid = s.grid;
     if (unroll) *unroll = s.unroll;
     return CFMM_OK;

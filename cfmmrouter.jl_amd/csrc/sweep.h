@@ -7,9 +7,10 @@
 
 namespace cfmm {
 
-constexpr int kBlock = 256;          // 4 wavefronts of 64 lanes
-constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kReduceCols = 16;      // tokens per reduce block (128 B of each partial row)
+constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
+constexpr int kBigBlock = 1024;      // 16 wavefronts: one or two fat blocks per CU, few partial rows
+constexpr int kReduceBlock = 256;
+constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
 constexpr int kMaxTokens = 8192;     // v + one bin copy must fit the 160 KiB LDS of a CU
 
 // SoA-of-pairs pool stores, one struct per pool family.  All pointers are device pointers.
@@ -36,7 +37,7 @@ struct SweepArgs {
     const double* v;             // [n] device
     int n;                       // n_tokens
     int n_pad;                   // n rounded up to even (LDS row pitch)
-    int copies;                  // private bin copies per block (1 or kWavesPerBlock)
+    int copies;                  // private bin copies per block (1 or one per wavefront)
     int64_t m;                   // pools in this segment
     double2* Delta;              // [m] segment base, may be null when !materialize
     double2* Lambda;
@@ -45,6 +46,7 @@ struct SweepArgs {
 };
 
 struct LaunchCfg {
+    int block;                   // kSmallBlock or kBigBlock
     int grid;
     int unroll;                  // 1, 2 or 4 pools per lane per tile
     size_t lds_bytes;
@@ -60,7 +62,7 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s);
 
-size_t sweep_lds_bytes(int n_pad, int copies);
+size_t sweep_lds_bytes(int n_pad, int copies, int block);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 
 } // namespace cfmm

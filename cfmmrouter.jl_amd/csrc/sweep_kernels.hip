@@ -53,9 +53,9 @@ struct ProductOps {
     ProductPools p;
     __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.gamma[i], p.Ai[i]}; }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    // All four closed forms exactly as written in the reference (:134-138).
+    __device__ __forceinline__ void solve_full(double R1, double R2, double g, double v1, double v2, Trade& t) const
     {
-        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double k = R1 * R2;          // :132
         const double m12 = v2 / v1;        // m of :134/:138
         const double m21 = v1 / v2;        // m of :135/:137
@@ -65,6 +65,34 @@ struct ProductOps {
         t.d2 = max0(sqrt(gm21 * k) - R2) / g;   // :125,:135
         t.l1 = max0(R1 - sqrt(k / gm21));       // :126,:137
         t.l2 = max0(R2 - sqrt(k / gm12));       // :126,:138
+    }
+
+    // At most one direction trades (Δ₁,Λ₂ > 0 ⇔ γ·v₂R₂ > v₁R₁;  Δ₂,Λ₁ > 0 ⇔ γ·v₁R₁ > v₂R₂), so only
+    // that direction's two closed forms are evaluated -- with the reference's own expressions on
+    // the selected operands, hence bit-identical values.  The predicates carry a 1e-12 relative
+    // margin (>> the 1e-16 rounding of the forms), so a direction is only skipped where the
+    // reference's max(·, 0) provably clamps to 0; the (measure-zero) overlap runs the full forms.
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
+        constexpr double kMargin = 1.0 + 1e-12;
+        const double a = v1 * R1, b = v2 * R2;
+        const bool p1 = (g * b) * kMargin >= a;    // direction 1 possibly active
+        const bool p2 = (g * a) * kMargin >= b;    // direction 2 possibly active
+        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (p1 != p2) {
+            const double k = R1 * R2;                          // :132
+            const double gm = g * ((p1 ? v2 : v1) / (p1 ? v1 : v2));   // γ*m, m = v_out / v_in
+            const double r_in = p1 ? R1 : R2, r_out = p1 ? R2 : R1;
+            const double d = max0(sqrt(gm * k) - r_in) / g;    // :125
+            const double l = max0(r_out - sqrt(k / gm));       // :126
+            t.d1 = p1 ? d : 0.0;
+            t.d2 = p1 ? 0.0 : d;
+            t.l1 = p1 ? 0.0 : l;
+            t.l2 = p1 ? l : 0.0;
+        } else if (p1) {   // both within the margin (γ ≈ 1 at the no-arbitrage price) or NaN inputs
+            solve_full(R1, R2, g, v1, v2, t);
+        }
     }
 };
 
@@ -91,16 +119,34 @@ struct GeoMeanOps {
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i]}; }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
+    // Same idea as ProductOps::solve: Δ₁,Λ₂ > 0 ⇔ γ·m₁₂·η·R₂ > R₁ and Δ₂,Λ₁ > 0 ⇔ γ·m₂₁·R₁/η > R₂
+    // (the bases of :180 exceed r2^(η+1)); only the live direction's two forms (4 pow instead of
+    // 8) are evaluated, with the reference's expressions on the selected operands.
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
     {
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double eta = r.w.x / r.w.y;        // :188
         const double ieta = 1.0 / eta;
         const double m12 = v2 / v1, m21 = v1 / v2;
-        t.d1 = geom_arb_delta(m12, R2, R1, eta, g);   // :190
-        t.d2 = geom_arb_delta(m21, R1, R2, ieta, g);  // :191
-        t.l1 = geom_arb_lambda(m21, R1, R2, ieta, g); // :193
-        t.l2 = geom_arb_lambda(m12, R2, R1, eta, g);  // :194
+        constexpr double kMargin = 1.0 + 1e-11;  // pow is good to ~1 ulp; keep a wide margin
+        const bool p1 = (((g * m12) * eta) * R2) * kMargin >= R1;
+        const bool p2 = (((g * m21) * ieta) * R1) * kMargin >= R2;
+        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (p1 != p2) {
+            const double m = p1 ? m12 : m21, e = p1 ? eta : ieta;
+            const double ra = p1 ? R2 : R1, rb = p1 ? R1 : R2;
+            const double d = geom_arb_delta(m, ra, rb, e, g);    // :190 / :191
+            const double l = geom_arb_lambda(m, ra, rb, e, g);   // :194 / :193
+            t.d1 = p1 ? d : 0.0;
+            t.d2 = p1 ? 0.0 : d;
+            t.l1 = p1 ? 0.0 : l;
+            t.l2 = p1 ? l : 0.0;
+        } else if (p1) {
+            t.d1 = geom_arb_delta(m12, R2, R1, eta, g);   // :190
+            t.d2 = geom_arb_delta(m21, R1, R2, ieta, g);  // :191
+            t.l1 = geom_arb_lambda(m21, R1, R2, ieta, g); // :193
+            t.l2 = geom_arb_lambda(m12, R2, R1, eta, g);  // :194
+        }
     }
 };
 
@@ -205,13 +251,15 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
     }
 }
 
-template <class Ops, bool MAT, int U>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(Ops ops, SweepArgs a)
+template <class Ops, bool MAT, int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
+    constexpr int kBlock = BLOCK;
+    constexpr int kWaves = BLOCK / 64;
     extern __shared__ double lds[];
     double* v_s = lds;                         // [n_pad]
     double* bins = lds + a.n_pad;              // [copies][n_pad]
-    double* wsum = bins + (size_t)a.copies * a.n_pad; // [kWavesPerBlock]
+    double* wsum = bins + (size_t)a.copies * a.n_pad; // [kWaves]
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
 
@@ -269,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Ops ops, SweepArgs a)
     }
     if (tid == 0) {
         double s = wsum[0];
-        for (int w = 1; w < kWavesPerBlock; ++w) s += wsum[w];
+        for (int w = 1; w < kWaves; ++w) s += wsum[w];
         row[a.n] = s;
     }
 }
@@ -277,17 +325,27 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Ops ops, SweepArgs a)
 // Folds the per-block partial rows: out[j] = sum_rows partials[row][j].  One block owns
 // kReduceCols adjacent columns; its 256 lanes are 16 row-lanes x 16 columns.  Each lane sums
 // its rows in increasing order, the 16 row-lanes are then folded in increasing order.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int rows,
-                                                         int n1, double* __restrict__ out)
+__global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int rows,
+                                                                int n1, double* __restrict__ out)
 {
-    __shared__ double red[kBlock / kReduceCols][kReduceCols + 1];
+    constexpr int kRowLanes = kReduceBlock / kReduceCols;
+    constexpr int kBatch = 8;   // independent loads in flight per lane
+    __shared__ double red[kRowLanes][kReduceCols + 1];
     const int c = threadIdx.x % kReduceCols;
     const int r = threadIdx.x / kReduceCols;
     const int col = blockIdx.x * kReduceCols + c;
-    constexpr int kRowLanes = kBlock / kReduceCols;
     double s = 0.0;
     if (col < n1) {
-        for (int row = r; row < rows; row += kRowLanes) s += partials[(size_t)row * n1 + col];
+        const double* p = partials + col;
+        int row = r;
+        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
+            double x[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) s += x[b];
+        }
+        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
     }
     red[r][c] = s;
     __syncthreads();
@@ -301,21 +359,24 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restri
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-size_t sweep_lds_bytes(int n_pad, int copies)
+size_t sweep_lds_bytes(int n_pad, int copies, int block)
 {
-    return ((size_t)n_pad * (1 + copies) + kWavesPerBlock) * sizeof(double);
+    return ((size_t)n_pad * (1 + copies) + block / 64) * sizeof(double);
 }
 
 template <class Ops>
 static hipError_t set_lds_attr(size_t bytes)
 {
     hipError_t e;
-#define CFMM_SET(MAT, U)                                                                              \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, U>),                \
+#define CFMM_SET(MAT, U, B)                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, U, B>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                  \
     if (e != hipSuccess) return e;
-    CFMM_SET(true, 1) CFMM_SET(true, 2) CFMM_SET(true, 4)
-    CFMM_SET(false, 1) CFMM_SET(false, 2) CFMM_SET(false, 4)
+#define CFMM_SET_B(B)                                                                                 \
+    CFMM_SET(true, 1, B) CFMM_SET(true, 2, B) CFMM_SET(true, 4, B)                                    \
+    CFMM_SET(false, 1, B) CFMM_SET(false, 2, B) CFMM_SET(false, 4, B)
+    CFMM_SET_B(256) CFMM_SET_B(1024)
+#undef CFMM_SET_B
 #undef CFMM_SET
     return hipSuccess;
 }
@@ -329,12 +390,11 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     return set_lds_attr<UniV3Ops>(max_lds_bytes);
 }
 
-template <class Ops>
-static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+template <class Ops, int B>
+static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (a.m <= 0) return hipSuccess;
-    dim3 g(c.grid), b(kBlock);
-#define CFMM_GO(MAT, U) hipLaunchKernelGGL((sweep_kernel<Ops, MAT, U>), g, b, c.lds_bytes, s, ops, a)
+    dim3 g(c.grid), b(B);
+#define CFMM_GO(MAT, U) hipLaunchKernelGGL((sweep_kernel<Ops, MAT, U, B>), g, b, c.lds_bytes, s, ops, a)
     if (mat) {
         if (c.unroll == 4) CFMM_GO(true, 4);
         else if (c.unroll == 2) CFMM_GO(true, 2);
@@ -345,6 +405,14 @@ static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg
         else CFMM_GO(false, 1);
     }
 #undef CFMM_GO
+}
+
+template <class Ops>
+static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    if (a.m <= 0) return hipSuccess;
+    if (c.block == 1024) launch_block<Ops, 1024>(ops, a, c, mat, s);
+    else launch_block<Ops, 256>(ops, a, c, mat, s);
     return hipGetLastError();
 }
 
@@ -363,7 +431,7 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
 
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s)
 {
-    dim3 g((n1 + kReduceCols - 1) / kReduceCols), b(kBlock);
+    dim3 g((n1 + kReduceCols - 1) / kReduceCols), b(kReduceBlock);
     hipLaunchKernelGGL(reduce_partials, g, b, 0, s, partials, rows, n1, out);
     return hipGetLastError();
 }

@@ -60,8 +60,10 @@ const char* cfmm_version(void);
  * context's own stream.  NULL restores the context's stream. */
 int cfmm_set_stream(cfmm_ctx* ctx, void* hip_stream);
 
-/* Tuning / instrumentation knobs: "max_grid", "unroll", "bin_copies", "time_kernels",
- * "nt_stores".  Unknown keys are CFMM_ERR_INVALID_ARG. */
+/* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 1024 threads),
+ * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
+ * per block, 2 = one per wavefront), "time_kernels", "nt_stores".  Unknown keys are
+ * CFMM_ERR_INVALID_ARG. */
 int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);
 int cfmm_get_option(const cfmm_ctx* ctx, const char* key, int64_t* value);
 
@@ -130,10 +132,10 @@ int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lamb
 int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
                       int64_t* reduce_launches, double* reduce_ms);
 
-/* Number of segments and their description (kind, pool count, grid, unroll). */
+/* Number of segments and their description (kind, pool count, launch geometry). */
 int32_t cfmm_segment_count(const cfmm_ctx* ctx);
-int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* grid,
-                      int32_t* unroll);
+int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* block,
+                      int32_t* grid, int32_t* unroll);
 
 #ifdef __cplusplus
 }

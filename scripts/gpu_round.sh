@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box session: parity tests, bench lines, rocprof kernel stats.  Every step is bounded.
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 < /dev/null; tail -4 gpurun_out/pytest_gpu.log
+for w in ${WORKLOADS:-config3 product1m config2 config5}; do
+  timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu --workload $w > gpurun_out/bench_$w.log 2>&1 < /dev/null
+  timeout 20 python scripts/show_bench.py gpurun_out/bench_$w.log $w < /dev/null
+done
+if [ -n "$TUNE" ]; then
+  for t in $TUNE; do timeout 250 python scripts/tune.py $t > gpurun_out/tune_$t.txt 2>&1 < /dev/null; done
+fi
+if [ -n "$PROF" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  for w in $PROF; do
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o $w -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --workload $w > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1 < /dev/null
+    f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$w -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && head -8 "$f"
+  done
+fi
