@@ -77,6 +77,7 @@ struct cfmm_ctx {
     int64_t opt_bin_copies = 0;  // 0 = auto, 1 = one shared copy, 2 = one copy per wavefront
     int64_t opt_time_kernels = 0;
     int64_t opt_nt_stores = 0;
+    int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -156,8 +157,8 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
 {
     int U = (int)c->opt_unroll;
     if (U != 1 && U != 2 && U != 4) {
-        if (s.kind == CFMM_KIND_PRODUCT) U = s.m >= (1 << 19) ? 4 : (s.m >= (1 << 18) ? 2 : 1);
-        else U = s.m >= (1 << 20) ? 2 : 1; // pow / tick walks carry more live state per pool
+        U = 1; // measured on MI355X (scripts/tune.py): one pool per lane per tile is fastest for
+               // every family; 16 wavefronts per CU already cover the HBM latency
     }
     s.unroll = U;
     const int64_t tiles_small = std::max<int64_t>(1, (s.m + (int64_t)kSmallBlock * U - 1) / ((int64_t)kSmallBlock * U));
@@ -260,7 +261,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         hipError_t e = hipSuccess;
         switch (s.kind) {
         case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
-        case CFMM_KIND_GEOMEAN: e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
+        case CFMM_KIND_GEOMEAN: e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream); break;
         case CFMM_KIND_UNIV3:
             e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
             break;
@@ -406,6 +407,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "bin_copies")) return &c->opt_bin_copies;
     if (!std::strcmp(key, "time_kernels")) return &c->opt_time_kernels;
     if (!std::strcmp(key, "nt_stores")) return &c->opt_nt_stores;
+    if (!std::strcmp(key, "geomean_exact")) return &c->opt_geomean_exact;
     return nullptr;
 }
 

@@ -24,6 +24,7 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* w;            // [m] {w1, w2}
     const double* gamma;
     const int2* Ai;
+    int reference_order;         // 1: evaluate with pow in the reference's operation order
 };
 struct UniV3Pools {              // src/cfmms.jl:226-245, ticks in CSR form
     const double2* pg;           // [m] {current_price, gamma}

@@ -150,6 +150,41 @@ struct GeoMeanOps {
     }
 };
 
+// Log-space evaluation of the same two closed forms (default for GeometricMeanTwoCoin).
+// With c = γ·m·e·r_a (the pow-free factor of :180), l_x = log x:
+//     (c·r_b^e)^(1/(e+1))                    = exp((l_c + e·l_b) / (e+1))
+//     ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = exp((l_a + e·(l_b − l_c + l_a)) / (1+e))
+// i.e. 3 log + 2 exp per trading pool instead of 4 pow.  The exponent carries an absolute
+// rounding error of a few 1e-16·max(1, e·|l|)/(e+1), so trades agree with the reference-order
+// forms to ~1e-15 of the reserve scale (asserted at 1e-12 in tests/test_gpu_parity.py).
+struct GeoMeanLogOps : GeoMeanOps {
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
+        const double eta = r.w.x / r.w.y;        // :188
+        const double ieta = 1.0 / eta;
+        const double m12 = v2 / v1, m21 = v1 / v2;
+        const double c1 = ((g * m12) * eta) * R2;    // direction 1 trades iff c1 > R1
+        const double c2 = ((g * m21) * ieta) * R1;   // direction 2 trades iff c2 > R2
+        const bool p1 = c1 > R1, p2 = c2 > R2;
+        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (p1 != p2) {
+            const double e = p1 ? eta : ieta, c = p1 ? c1 : c2;
+            const double ra = p1 ? R2 : R1, rb = p1 ? R1 : R2;
+            const double la = log(ra), lb = log(rb), lc = log(c);
+            const double inv = 1.0 / (e + 1.0);
+            const double d = max0(exp((lc + e * lb) * inv) - rb) / g;
+            const double l = max0(ra - exp((la + e * ((lb - lc) + la)) * inv));
+            t.d1 = p1 ? d : 0.0;
+            t.d2 = p1 ? 0.0 : d;
+            t.l1 = p1 ? 0.0 : l;
+            t.l2 = p1 ? l : 0.0;
+        } else if (p1) {   // γ > 1: both directions "trade"; keep the reference's arithmetic
+            GeoMeanOps::solve(r, v1, v2, t);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // UniV3 / BoundedProduct -- src/cfmms.jl:294-395 (lane per pool, serial tick walk)
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +422,8 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     if (e != hipSuccess) return e;
     e = set_lds_attr<GeoMeanOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
+    e = set_lds_attr<GeoMeanLogOps>(max_lds_bytes);
+    if (e != hipSuccess) return e;
     return set_lds_attr<UniV3Ops>(max_lds_bytes);
 }
 
@@ -422,7 +459,10 @@ hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    return launch_any(GeoMeanOps{p}, a, c, mat, s);
+    if (p.reference_order) return launch_any(GeoMeanOps{p}, a, c, mat, s);
+    GeoMeanLogOps ops;
+    ops.p = p;
+    return launch_any(ops, a, c, mat, s);
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {

@@ -62,7 +62,9 @@ int cfmm_set_stream(cfmm_ctx* ctx, void* hip_stream);
 
 /* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 1024 threads),
  * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
- * per block, 2 = one per wavefront), "time_kernels", "nt_stores".  Unknown keys are
+ * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "geomean_exact" (1 = evaluate
+ * GeometricMeanTwoCoin with pow in the reference's operation order instead of the default
+ * log-space form; both are within 1e-12 of the reference).  Unknown keys are
  * CFMM_ERR_INVALID_ARG. */
 int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);
 int cfmm_get_option(const cfmm_ctx* ctx, const char* key, int64_t* value);

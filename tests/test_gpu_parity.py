@@ -101,15 +101,17 @@ def test_product_launch_variants(unroll, copies, block):
     assert rel_to_max(psi, psio) <= REDUCE_TOL
 
 
+@pytest.mark.parametrize("exact", [0, 1])   # 0: log-space forms (default), 1: pow in reference order
 @pytest.mark.parametrize("m,n", [(1, 2), (513, 16), (50_000, 256)])
-def test_geomean_sweep(m, n):
+def test_geomean_sweep(m, n, exact):
     b = synth.geomean_pools(m, n, seed=m)
     v = synth.sweep_prices(n, seed=n)
-    D, L, psi, acc = device_sweep([b], n, v)
+    D, L, psi, acc = device_sweep([b], n, v, geomean_exact=exact)
     Do, Lo, psio, acco = oracle_sweep([b], n, v)
     scale = np.max(b.R, axis=1, keepdims=True)
     assert np.max(np.abs(D - Do) / scale) <= GEOM_RTOL
     assert np.max(np.abs(L - Lo) / scale) <= GEOM_RTOL
+    assert np.array_equal(D > 0, Do > 0) or np.max(np.abs(D - Do)[(D > 0) != (Do > 0)] / scale.repeat(2, 1)[(D > 0) != (Do > 0)]) <= 1e-14
     assert rel_to_max(psi, psio) <= 1e-11
     assert abs(acc - acco) <= 1e-10 * max(abs(acco), 1.0)
 
@@ -124,6 +126,24 @@ def test_univ3_sweep_bit_exact(m, n, t):
     np.testing.assert_array_equal(L, Lo)
     assert m == 1 or np.count_nonzero(D) > 0
     assert rel_to_max(psi, psio) <= REDUCE_TOL
+
+
+def test_geomean_extreme_weights_and_fees():
+    """η = w₁/w₂ from 1/99 to 99, γ down to 0.5, reserves over 12 decades: log-space vs reference order."""
+    rng = np.random.default_rng(11)
+    m, n = 20_000, 12
+    w1 = rng.uniform(0.01, 0.99, m)
+    R = 10.0 ** rng.uniform(-6, 6, (m, 2))
+    γ = rng.choice([0.5, 0.9, 0.997, 1.0], m)
+    b = cr.GeometricMeanTwoCoin.batch(R, np.stack([w1, 1 - w1], 1), γ, synth.token_pairs(3, 1, m, n))
+    v = 10.0 ** rng.uniform(-3, 3, n)
+    Do, Lo, psio, _ = oracle_sweep([b], n, v)
+    scale = np.max(R, axis=1, keepdims=True)
+    for exact in (0, 1):
+        D, L, psi, _ = device_sweep([b], n, v, geomean_exact=exact)
+        assert np.max(np.abs(D - Do) / np.maximum(scale, Do)) <= 1e-11
+        assert np.max(np.abs(L - Lo) / scale) <= 1e-11
+        assert rel_to_max(psi, psio) <= 1e-10
 
 
 def test_mixed_segments_and_router_order():
