@@ -203,6 +203,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):
+    # pageable v in, Ψ/acc out over PCIe, one stream sync -- never the headline value
+    be.ctx.set_stream(0)
+    host = {}
+    if world == 1:
+        for name, fn in (("eval", lambda: be.eval(v)), ("find_arb", lambda: be.find_arb(v))):
+            for _ in range(5):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                fn()
+            host[name + "_us"] = 1e6 * (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        be.trades()
+        host["get_trades_ms"] = 1e3 * (time.perf_counter() - t0)
+    be.ctx.set_stream(stream.cuda_stream)
+
     # sanity: the timed path produced the oracle's netflows (spot check on rank 0, small sample)
     psi_dev = out_t.cpu().numpy()
 
@@ -238,6 +255,9 @@ def main():
                             "second K-step pass; the bracket adds ~2.5 us to each ~10 us kernel vs rocprofv3 "
                             "(profiles/), so frac is a lower bound"},
     }
+    if host:
+        host["pools_per_s_host_call_find_arb"] = m_rank / (host["find_arb_us"] * 1e-6)
+        line["host_boundary"] = host
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(batches, n, v)
         # check the device result of the timed path against the oracle's netflows

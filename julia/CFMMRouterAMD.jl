@@ -1,0 +1,166 @@
+# CFMMRouterAMD.jl -- the Julia host side of the MI355X drop-in: a `Router`-compatible type whose
+# `find_arb!` sweep and Ψ/dual reductions run in libcfmm_amd.so (include/cfmm_amd.h) while
+# LBFGSB.jl keeps driving the outer loop exactly as in CFMMRouter.jl's src/router.jl:58-108.
+#
+# STATUS: written against Julia 1.7+/CFMMRouter v0.3.1 but NOT EXECUTED -- there is no Julia
+# toolchain in the build image.  The same call sequence is exercised through the Python mirror
+# (cfmmrouter.jl_amd/router.py) and tests/test_gpu_parity.py.
+#
+# Usage (drop-in for the README quick start):
+#     using CFMMRouter, CFMMRouterAMD
+#     router = AMDRouter(LinearNonnegative(prices), [equal_pool, unequal_small_pool], 2)
+#     route!(router); Ψ = netflows(router)
+module CFMMRouterAMD
+
+using CFMMRouter
+using CFMMRouter: CFMM, ProductTwoCoin, GeometricMeanTwoCoin, UniV3, Objective
+using LBFGSB
+import CFMMRouter: route!, netflows, netflows!, find_arb!
+
+export AMDRouter
+
+const LIB = get(ENV, "CFMM_AMD_LIB", "libcfmm_amd.so")
+
+struct CFMMAMDError <: Exception
+    code::Cint
+    msg::String
+end
+
+function check(ctx::Ptr{Cvoid}, rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:cfmm_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+    rc == -1 && throw(ArgumentError(msg))          # CFMM_ERR_INVALID_ARG == the reference's ArgumentError
+    throw(CFMMAMDError(rc, msg))
+end
+
+# Same readable fields as CFMMRouter.Router (src/router.jl:4-10): objective, cfmms, Δs, Λs, v.
+mutable struct AMDRouter{O,T}
+    objective::O
+    cfmms::Vector{CFMM{T}}
+    Δs::Vector{Vector{T}}
+    Λs::Vector{Vector{T}}
+    v::Vector{T}
+    ctx::Ptr{Cvoid}
+    order::Vector{Int}          # packed position -> index into cfmms (pools are grouped by family)
+    Ψ::Vector{T}
+    acc::Base.RefValue{T}
+end
+
+# Router(objective, cfmms, n_tokens) -- src/router.jl:18-36
+function AMDRouter(objective::O, cfmms::Vector{C}, n_tokens; device::Integer=0) where {O<:Objective,C<:CFMM{Float64}}
+    ctxref = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:cfmm_ctx_create, LIB), Cint, (Cint, Int32, Ref{Ptr{Cvoid}}), device, n_tokens, ctxref)
+    check(Ptr{Cvoid}(C_NULL), rc)
+    ctx = ctxref[]
+    order = Int[]
+    # --- ProductTwoCoin segment (src/cfmms.jl:101-111) ---
+    idx = findall(c -> c isa ProductTwoCoin, cfmms)
+    if !isempty(idx)
+        R = Float64[c.R[j] for j in 1:2, c in cfmms[idx]]            # 2×m column-major == [m][2] row-major
+        γ = Float64[c.γ for c in cfmms[idx]]
+        Ai = Int32[c.Ai[j] - 1 for j in 1:2, c in cfmms[idx]]        # 1-based -> 0-based
+        GC.@preserve R γ Ai check(ctx, ccall((:cfmm_pools_add_product, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}), ctx, length(idx), R, γ, Ai))
+        append!(order, idx)
+    end
+    # --- GeometricMeanTwoCoin segment (src/cfmms.jl:152-165) ---
+    idx = findall(c -> c isa GeometricMeanTwoCoin, cfmms)
+    if !isempty(idx)
+        R = Float64[c.R[j] for j in 1:2, c in cfmms[idx]]
+        w = Float64[c.w[j] for j in 1:2, c in cfmms[idx]]
+        γ = Float64[c.γ for c in cfmms[idx]]
+        Ai = Int32[c.Ai[j] - 1 for j in 1:2, c in cfmms[idx]]
+        GC.@preserve R w γ Ai check(ctx, ccall((:cfmm_pools_add_geomean, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}), ctx, length(idx), R, w, γ, Ai))
+        append!(order, idx)
+    end
+    # --- UniV3 segment, ticks in CSR form (src/cfmms.jl:226-245) ---
+    idx = findall(c -> c isa UniV3, cfmms)
+    if !isempty(idx)
+        cp = Float64[c.current_price for c in cfmms[idx]]
+        γ = Float64[c.γ for c in cfmms[idx]]
+        Ai = Int32[c.Ai[j] - 1 for j in 1:2, c in cfmms[idx]]
+        off = Int64[0; cumsum(length(c.lower_ticks) for c in cfmms[idx])]
+        ticks = reduce(vcat, (Float64.(c.lower_ticks) for c in cfmms[idx]))
+        liq = reduce(vcat, (Float64.(c.liquidity) for c in cfmms[idx]))
+        GC.@preserve cp γ Ai off ticks liq check(ctx, ccall((:cfmm_pools_add_univ3, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+            ctx, length(idx), cp, γ, Ai, off, ticks, liq))
+        append!(order, idx)
+    end
+    length(order) == length(cfmms) || throw(ArgumentError("unsupported CFMM type in cfmms"))
+    Δs = [zeros(2) for _ in cfmms]; Λs = [zeros(2) for _ in cfmms]    # zerotrade, src/router.jl:23-26
+    r = AMDRouter{O,Float64}(objective, convert(Vector{CFMM{Float64}}, cfmms), Δs, Λs, zeros(n_tokens), ctx, order,
+                             zeros(n_tokens), Ref(0.0))
+    finalizer(x -> ccall((:cfmm_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ctx), r)
+    return r
+end
+
+# find_arb!(r::Router, v) -- src/router.jl:38-42: materialising device sweep, then r.Δs/r.Λs are filled
+function find_arb!(r::AMDRouter, v)
+    vv = Vector{Float64}(v)
+    GC.@preserve vv check(r.ctx, ccall((:cfmm_find_arb, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), r.ctx, vv))
+    m = length(r.cfmms)
+    D = Matrix{Float64}(undef, 2, m); L = Matrix{Float64}(undef, 2, m)
+    GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
+    for (k, i) in enumerate(r.order)
+        r.Δs[i] .= @view D[:, k]; r.Λs[i] .= @view L[:, k]
+    end
+    check(r.ctx, ccall((:cfmm_netflows, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), r.ctx, r.Ψ))
+    check(r.ctx, ccall((:cfmm_dual_value, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), r.ctx, r.acc))
+    return nothing
+end
+
+# the fused evaluation used inside fn/g! (no O(m) trade write-back)
+function eval_pools!(r::AMDRouter, v)
+    vv = Vector{Float64}(v)
+    GC.@preserve vv check(r.ctx, ccall((:cfmm_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+                                       r.ctx, vv, r.Ψ, r.acc))
+    return nothing
+end
+
+# route!(r; ...) -- src/router.jl:58-108, line for line, with the two O(m) loops replaced by Ψ/acc
+function route!(r::AMDRouter; v=nothing, verbose=false, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000)
+    optimizer = L_BFGS_B(length(r.v), 17)
+    if isnothing(v)
+        r.v .= ones(length(r.v)) / length(r.v)
+    else
+        r.v .= v
+    end
+    bounds = zeros(3, length(r.v))
+    bounds[1, :] .= 2
+    bounds[2, :] .= CFMMRouter.lower_limit(r.objective)
+    bounds[3, :] .= CFMMRouter.upper_limit(r.objective)
+
+    function fn(v)
+        if !all(v .== r.v)
+            eval_pools!(r, v)
+            r.v .= v
+        end
+        return CFMMRouter.f(r.objective, v) + r.acc[]          # src/router.jl:79-85
+    end
+    function g!(G, v)
+        G .= 0
+        if !all(v .== r.v)
+            eval_pools!(r, v)
+            r.v .= v
+        end
+        CFMMRouter.grad!(G, r.objective, v)
+        G .+= r.Ψ                                               # src/router.jl:98-100
+    end
+
+    eval_pools!(r, r.v)                                         # src/router.jl:104
+    _, vopt = optimizer(fn, g!, r.v, bounds, m=m, factr=factr, pgtol=pgtol, iprint=verbose ? 1 : -1,
+                        maxfun=maxfun, maxiter=maxiter)
+    r.v .= vopt
+    find_arb!(r, vopt)                                          # src/router.jl:107
+end
+
+# netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125
+function netflows!(ψ, r::AMDRouter)
+    ψ .= r.Ψ
+    return nothing
+end
+netflows(r::AMDRouter) = copy(r.Ψ)
+
+end # module

@@ -17,3 +17,20 @@ if [ -n "$PROF" ]; then
     [ -n "$f" ] && head -8 "$f"
   done
 fi
+if [ -n "$PMC" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  for w in $PMC; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${w}_$c -o $w -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu --workload $w > $GRAFT_REPO_ROOT/gpurun_out/pmc_${w}_$c.log 2>&1 < /dev/null
+    done
+  done
+  cd $GRAFT_REPO_ROOT
+  timeout 60 python scripts/pmc_summary.py gpurun_out $PMC < /dev/null
+fi
+if [ -n "$FULL" ]; then
+  cd $GRAFT_REPO_ROOT
+  for w in $FULL; do
+    timeout 500 python bench.py --workload $w > gpurun_out/benchfull_$w.log 2>&1 < /dev/null
+    tail -1 gpurun_out/benchfull_$w.log | cut -c1-3000
+  done
+fi
