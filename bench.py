@@ -159,7 +159,8 @@ def main():
     for kv in args.opt:
         k, val = kv.split("=")
         be.ctx.set_option(k, int(val))
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # the sweep, the RCCL all-reduce and the events share it
+    torch.cuda.set_stream(stream)
     be.ctx.set_stream(stream.cuda_stream)
     v_t = torch.from_numpy(v).to("cuda")
     out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
@@ -205,7 +206,7 @@ def main():
 
     # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):
     # pageable v in, Ψ/acc out over PCIe, one stream sync -- never the headline value
-    be.ctx.set_stream(0)
+    be.ctx.reset_stream()
     host = {}
     if world == 1:
         for name, fn in (("eval", lambda: be.eval(v)), ("find_arb", lambda: be.find_arb(v))):

@@ -76,6 +76,7 @@ def lib():
     L.cfmm_last_error.restype = C.c_char_p
     L.cfmm_version.restype = C.c_char_p
     L.cfmm_set_stream.argtypes = [_ctx, C.c_void_p]
+    L.cfmm_reset_stream.argtypes = [_ctx]
     L.cfmm_set_option.argtypes = [_ctx, C.c_char_p, C.c_int64]
     L.cfmm_get_option.argtypes = [_ctx, C.c_char_p, _i64p]
     L.cfmm_pools_add_product.argtypes = [_ctx, C.c_int64, _f64p, _f64p, _i32p]
@@ -161,7 +162,11 @@ class Context:
 
     # -- configuration -------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
+        """Launch on exactly this hipStream_t handle (0 / None = HIP's default stream)."""
         self._check(self._L.cfmm_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        self._check(self._L.cfmm_reset_stream(self._h))
 
     def set_option(self, key: str, value: int):
         self._check(self._L.cfmm_set_option(self._h, key.encode(), int(value)))

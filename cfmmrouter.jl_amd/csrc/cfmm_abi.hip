@@ -45,6 +45,15 @@ struct Segment {
     int64_t row_off = 0; // first partial row
 };
 
+// A launch: either one segment (sweep_kernel) or up to kMaxMulti segments fused (sweep_multi).
+struct Group {
+    int first = 0, nseg = 1;
+    bool multi = false;
+    int block = kSmallBlock;
+    int grid = 0;       // total blocks of the launch
+    int64_t row_off = 0;
+};
+
 } // namespace
 
 struct cfmm_ctx {
@@ -54,6 +63,7 @@ struct cfmm_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<Segment> segs;
+    std::vector<Group> groups;
     int64_t m_total = 0;
     int64_t rows_total = 0;
 
@@ -78,6 +88,7 @@ struct cfmm_ctx {
     int64_t opt_time_kernels = 0;
     int64_t opt_nt_stores = 0;
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
+    int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -193,12 +204,52 @@ int ensure_geometry(cfmm_ctx* c)
 {
     if (!c->geometry_dirty) return CFMM_OK;
     int64_t rows = 0, trades = 0;
+    bool fusable = c->opt_fuse_segments != 0 && c->segs.size() >= 2;
+    bool any_big = false;
     for (auto& s : c->segs) {
         plan_segment(c, s);
-        s.row_off = rows;
         s.trade_off = trades;
-        rows += s.grid;
         trades += s.m;
+        fusable = fusable && s.unroll == 1;
+        any_big = any_big || s.block == kBigBlock;
+    }
+    c->groups.clear();
+    if (fusable) {
+        const int block = any_big ? kBigBlock : kSmallBlock;
+        for (size_t first = 0; first < c->segs.size(); first += kMaxMulti) {
+            Group g;
+            g.first = (int)first;
+            g.nseg = (int)std::min<size_t>(kMaxMulti, c->segs.size() - first);
+            g.multi = g.nseg >= 2;
+            g.block = block;
+            int64_t tiles = 1;
+            for (int k = 0; k < g.nseg; ++k) {
+                Segment& sg = c->segs[first + k];
+                sg.block = block;
+                tiles = std::max<int64_t>(tiles, (sg.m + block - 1) / block);
+            }
+            const int64_t cap = std::max<int64_t>(
+                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kBigBlock ? 512 : 2048)) / g.nseg);
+            const int per_seg = (int)std::min<int64_t>(tiles, cap);
+            for (int k = 0; k < g.nseg; ++k) c->segs[first + k].grid = per_seg;
+            g.grid = per_seg * g.nseg;
+            g.row_off = rows;
+            c->segs[first].row_off = rows;
+            rows += g.grid;
+            c->groups.push_back(g);
+        }
+    } else {
+        for (size_t i = 0; i < c->segs.size(); ++i) {
+            Segment& sg = c->segs[i];
+            Group g;
+            g.first = (int)i;
+            g.block = sg.block;
+            g.grid = sg.grid;
+            g.row_off = rows;
+            sg.row_off = rows;
+            rows += sg.grid;
+            c->groups.push_back(g);
+        }
     }
     c->rows_total = rows;
     c->m_total = trades;
@@ -240,18 +291,17 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     if (rc != CFMM_OK) return rc;
     const bool timed = c->opt_time_kernels != 0;
     HIP_TRY(c, hipSetDevice(c->device));
-    for (auto& s : c->segs) {
+    for (const Group& g : c->groups) {
         SweepArgs a;
         a.v = d_v;
         a.n = c->n;
         a.n_pad = c->n_pad;
-        a.copies = bin_copies(c, s.block);
-        a.m = s.m;
-        a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
-        a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
-        a.partials = c->d_partials + (size_t)s.row_off * (c->n + 1);
+        a.copies = bin_copies(c, g.block);
+        a.m = 0;
+        a.Delta = a.Lambda = nullptr;
+        a.partials = c->d_partials + (size_t)g.row_off * (c->n + 1);
         a.nt_stores = (int)c->opt_nt_stores;
-        LaunchCfg cfg{s.block, s.grid, s.unroll, sweep_lds_bytes(c->n_pad, a.copies, s.block)};
+        const size_t lds = sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) {
             ea = take_event(c);
@@ -259,12 +309,40 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             if (ea && eb) HIP_TRY(c, hipEventRecord(ea, c->stream));
         }
         hipError_t e = hipSuccess;
-        switch (s.kind) {
-        case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
-        case CFMM_KIND_GEOMEAN: e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream); break;
-        case CFMM_KIND_UNIV3:
-            e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
-            break;
+        if (g.multi) {
+            MultiArgs ma;
+            std::memset(&ma, 0, sizeof ma);
+            ma.nseg = g.nseg;
+            ma.common = a;
+            for (int k = 0; k < g.nseg; ++k) {
+                const Segment& s = c->segs[(size_t)g.first + k];
+                MultiSeg& ms = ma.seg[k];
+                ms.kind = s.kind;
+                ms.m = s.m;
+                ms.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
+                ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+                switch (s.kind) {
+                case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
+                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}; break;
+                }
+            }
+            e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
+        } else {
+            const Segment& s = c->segs[(size_t)g.first];
+            a.m = s.m;
+            a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
+            a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+            LaunchCfg cfg{g.block, g.grid, s.unroll, lds};
+            switch (s.kind) {
+            case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
+            case CFMM_KIND_GEOMEAN:
+                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
+                break;
+            default:
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
+                break;
+            }
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "sweep launch failed: %s", hipGetErrorString(e));
         if (timed && ea && eb) {
@@ -394,7 +472,14 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
 int cfmm_set_stream(cfmm_ctx* c, void* hip_stream)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = static_cast<hipStream_t>(hip_stream); // NULL is HIP's default (null) stream
+    return CFMM_OK;
+}
+
+int cfmm_reset_stream(cfmm_ctx* c)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    c->stream = c->own_stream;
     return CFMM_OK;
 }
 
@@ -408,6 +493,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "time_kernels")) return &c->opt_time_kernels;
     if (!std::strcmp(key, "nt_stores")) return &c->opt_nt_stores;
     if (!std::strcmp(key, "geomean_exact")) return &c->opt_geomean_exact;
+    if (!std::strcmp(key, "fuse_segments")) return &c->opt_fuse_segments;
     return nullptr;
 }
 
@@ -428,7 +514,8 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
         hipError_t e = prepare_kernels(max_lds(c));
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "prepare_kernels: %s", hipGetErrorString(e));
     }
-    if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block) c->geometry_dirty = true;
+    if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments)
+        c->geometry_dirty = true;
     return CFMM_OK;
 }
 

@@ -46,6 +46,26 @@ struct SweepArgs {
     int nt_stores;               // use non-temporal stores for Delta/Lambda
 };
 
+// One launch over up to kMaxMulti segments (sweep_multi).
+constexpr int kMaxMulti = 4;
+union AnyPools {
+    ProductPools p;
+    GeoMeanPools g;
+    UniV3Pools u;
+};
+struct MultiSeg {
+    int kind;
+    int64_t m;
+    AnyPools pools;
+    double2* Delta;
+    double2* Lambda;
+};
+struct MultiArgs {
+    int nseg;
+    MultiSeg seg[kMaxMulti];
+    SweepArgs common;            // v, n, n_pad, copies, partials (row 0 of this launch), nt_stores
+};
+
 struct LaunchCfg {
     int block;                   // kSmallBlock or kBigBlock
     int grid;
@@ -58,6 +78,10 @@ hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchC
 hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
                         hipStream_t s);
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
+                        hipStream_t s);
+
+// grid must be a multiple of ma.nseg: block b sweeps segment b % nseg and writes partial row b.
+hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool materialize,
                         hipStream_t s);
 
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.

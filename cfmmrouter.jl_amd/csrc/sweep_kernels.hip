@@ -286,8 +286,10 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
     }
 }
 
+// One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
+// partial row goes to partials[row].
 template <class Ops, bool MAT, int U, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
+__device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     constexpr int kBlock = BLOCK;
     constexpr int kWaves = BLOCK / 64;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 
     const int64_t tile_pools = (int64_t)kBlock * U;
     const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {
         const int64_t base = tile * tile_pools + tid;
         typename Ops::Raw raw[U];
         bool ok[U];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
     if ((tid & 63) == 0) wsum[wave] = acc;
     __syncthreads();
 
-    double* row = a.partials + (size_t)blockIdx.x * (a.n + 1);
+    double* row = a.partials + (size_t)row_id * (a.n + 1);
     for (int j = tid; j < a.n; j += kBlock) {
         double s = bins[j];
         for (int c = 1; c < a.copies; ++c) s += bins[(size_t)c * a.n_pad + j];
@@ -354,6 +356,45 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
         double s = wsum[0];
         for (int w = 1; w < kWaves; ++w) s += wsum[w];
         row[a.n] = s;
+    }
+}
+
+template <class Ops, bool MAT, int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
+{
+    sweep_body<Ops, MAT, U, BLOCK>(ops, a, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+// Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
+// HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean / UniV3 blocks are co-resident on
+// every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
+template <bool MAT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
+{
+    const int sidx = blockIdx.x % ma.nseg;
+    const int local = blockIdx.x / ma.nseg;
+    const int nblocks = gridDim.x / ma.nseg;
+    const MultiSeg& sg = ma.seg[sidx];
+    SweepArgs a = ma.common;
+    a.m = sg.m;
+    a.Delta = sg.Delta;
+    a.Lambda = sg.Lambda;
+    switch (sg.kind) {
+    case 0:
+        sweep_body<ProductOps, MAT, 1, BLOCK>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
+        break;
+    case 1:
+        if (sg.pools.g.reference_order) {
+            sweep_body<GeoMeanOps, MAT, 1, BLOCK>(GeoMeanOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
+        } else {
+            GeoMeanLogOps ops;
+            ops.p = sg.pools.g;
+            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK>(ops, a, local, nblocks, blockIdx.x);
+        }
+        break;
+    default:
+        sweep_body<UniV3Ops, MAT, 1, BLOCK>(UniV3Ops{sg.pools.u}, a, local, nblocks, blockIdx.x);
+        break;
     }
 }
 
@@ -416,8 +457,28 @@ static hipError_t set_lds_attr(size_t bytes)
     return hipSuccess;
 }
 
+hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool mat, hipStream_t s)
+{
+    dim3 g(grid);
+    if (block == kBigBlock) {
+        if (mat) hipLaunchKernelGGL((sweep_multi<true, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
+        else hipLaunchKernelGGL((sweep_multi<false, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
+    } else {
+        if (mat) hipLaunchKernelGGL((sweep_multi<true, kSmallBlock>), g, dim3(kSmallBlock), lds_bytes, s, ma);
+        else hipLaunchKernelGGL((sweep_multi<false, kSmallBlock>), g, dim3(kSmallBlock), lds_bytes, s, ma);
+    }
+    return hipGetLastError();
+}
+
 hipError_t prepare_kernels(size_t max_lds_bytes)
 {
+    hipError_t em;
+#define CFMM_SETM(MAT, B)                                                                             \
+    em = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_multi<MAT, B>),                     \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);         \
+    if (em != hipSuccess) return em;
+    CFMM_SETM(true, kBigBlock) CFMM_SETM(false, kBigBlock) CFMM_SETM(true, kSmallBlock) CFMM_SETM(false, kSmallBlock)
+#undef CFMM_SETM
     hipError_t e = set_lds_attr<ProductOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
     e = set_lds_attr<GeoMeanOps>(max_lds_bytes);

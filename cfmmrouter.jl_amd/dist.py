@@ -56,6 +56,7 @@ class ShardedBackend:
             self._v_pin = torch.empty(self.n_tokens, dtype=torch.float64).pin_memory()
             self._out_pin = torch.empty(self.n_tokens + 1, dtype=torch.float64).pin_memory()
             self._dev = dev
+            self._stream = torch.cuda.Stream(device=dev)   # sweep, all-reduce and copies share it
 
     def _reduce_host(self, psi, acc):
         t = self._torch.from_numpy(np.concatenate([psi, [acc]]))
@@ -68,8 +69,8 @@ class ShardedBackend:
             psi, acc = (self.local.find_arb if materialize else self.local.eval)(v)
             return self._reduce_host(psi, acc)
         torch = self._torch
-        with torch.cuda.device(self._dev):
-            stream = torch.cuda.current_stream()
+        with torch.cuda.device(self._dev), torch.cuda.stream(self._stream):
+            stream = self._stream
             self.local.ctx.set_stream(stream.cuda_stream)
             self._v_pin.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)))
             self._v.copy_(self._v_pin, non_blocking=True)
@@ -89,7 +90,7 @@ class ShardedBackend:
     def trades(self):
         """The LOCAL shard's trades (Δ, Λ), segment order."""
         if self._on_device:
-            self._torch.cuda.current_stream().synchronize()
+            self._stream.synchronize()
         return self.local.trades()
 
     def close(self):

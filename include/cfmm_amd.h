@@ -57,12 +57,15 @@ const char* cfmm_last_error(const cfmm_ctx* ctx);
 const char* cfmm_version(void);
 
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * context's own stream.  NULL restores the context's stream. */
+ * context's own non-blocking stream.  NULL means HIP's default (null) stream -- exactly the
+ * handle given is used.  cfmm_reset_stream returns to the context's own stream. */
 int cfmm_set_stream(cfmm_ctx* ctx, void* hip_stream);
+int cfmm_reset_stream(cfmm_ctx* ctx);
 
 /* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 1024 threads),
  * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
- * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "geomean_exact" (1 = evaluate
+ * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "fuse_segments" (default 1: all
+ * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate
  * GeometricMeanTwoCoin with pow in the reference's operation order instead of the default
  * log-space form; both are within 1e-12 of the reference).  Unknown keys are
  * CFMM_ERR_INVALID_ARG. */

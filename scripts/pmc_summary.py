@@ -23,16 +23,20 @@ for w in workloads:
                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         per[c] = {k: sum(v) / len(v) for k, v in acc.items() if v}
     kernels = sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]))
-    tot = 0.0
-    detail = {}
-    for k in kernels:
-        if "sweep_kernel" not in k:
-            continue
-        f, wr = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
-        b = (2.0 * f + wr) * 1024.0
-        detail[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": b}
-        tot += b
-    out[w] = tot if detail else None
-    out[w + "_detail"] = detail
-    print(w, "traffic bytes/step =", tot, json.dumps(detail)[:600])
+    for variant, tag in (("materialising", " true,"), ("fused", " false,")):
+        tot = 0.0
+        detail = {}
+        for k in kernels:
+            if "sweep" not in k or tag not in k:
+                continue
+            f, wr = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
+            b = (2.0 * f + wr) * 1024.0
+            detail[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": b}
+            tot += b
+        key = w if variant == "materialising" else w + "_fused"
+        out[key] = tot if detail else None
+        out[key + "_detail"] = detail
+        print(key, "traffic bytes/step =", tot)
+        for k, d in detail.items():
+            print("   ", k[:100], d)
 json.dump(out, open(os.path.join(root, "traffic.json"), "w"), indent=1)

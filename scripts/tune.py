@@ -18,7 +18,8 @@ gen = {"product": synth.product_pools, "geomean": synth.geomean_pools, "bounded"
 b = gen(m, n, seed=1234)
 v = synth.sweep_prices(n, seed=1234)
 be = cr.DeviceBackend(n, [b])
-stream = torch.cuda.current_stream()
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
 be.ctx.set_stream(stream.cuda_stream)
 v_t = torch.from_numpy(v).to("cuda")
 out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")

@@ -171,6 +171,26 @@ def test_mixed_segments_and_router_order():
     r.close()
 
 
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_many_segments_one_launch(fuse):
+    """6 segments (> kMaxMulti = 4 per launch) of all three families, fused and per-segment launches."""
+    n = 40
+    segs = [synth.product_pools(3000, n, 1), synth.geomean_pools(1500, n, 2), synth.univ3_pools(700, n, 6, 3),
+            synth.product_pools(10, n, 4), synth.bounded_product_pools(2500, n, 5), synth.geomean_pools(1, n, 6)]
+    v = synth.sweep_prices(n, seed=2, spread=0.7)
+    D, L, psi, acc = device_sweep(segs, n, v, fuse_segments=fuse)
+    Do, Lo, psio, acco = oracle_sweep(segs, n, v)
+    scale = 1e3
+    assert np.max(np.abs(D - Do)) <= 1e-12 * max(scale, np.max(Do))
+    assert np.max(np.abs(L - Lo)) <= 1e-12 * max(scale, np.max(Lo))
+    np.testing.assert_array_equal(D[:3000], Do[:3000])                 # product rows stay bit-exact
+    np.testing.assert_array_equal(D[4500:5200], Do[4500:5200])         # univ3 rows stay bit-exact
+    assert rel_to_max(psi, psio) <= 1e-11
+    assert abs(acc - acco) <= 1e-10 * max(abs(acco), 1.0)
+    D2, L2, psi2, _ = device_sweep(segs, n, v, materialize=False, fuse_segments=fuse)
+    np.testing.assert_array_equal(psi2, psi)
+
+
 def test_fused_equals_materialised_and_deterministic():
     m, n = 200_000, 64
     b = synth.product_pools(m, n, seed=5)
