@@ -32,6 +32,8 @@ struct Segment {
     // device arrays (owned)
     double2* R = nullptr;
     double2* w = nullptr;
+    double2* ew = nullptr;   // geomean: {η, 1/(η+1)}
+    double2* lR = nullptr;   // geomean: {log R1, log R2}
     double* gamma = nullptr;
     int2* Ai = nullptr;
     double2* pg = nullptr;
@@ -135,6 +137,7 @@ int upload(cfmm_ctx* c, T** dst, const void* src, size_t count)
 void free_segment(Segment& s)
 {
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
+    (void)hipFree(s.ew); (void)hipFree(s.lR);
     (void)hipFree(s.pg); (void)hipFree(s.span); (void)hipFree(s.cur_tick); (void)hipFree(s.ticks);
     s = Segment{};
 }
@@ -323,7 +326,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
-                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}; break;
+                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
                 default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}; break;
                 }
             }
@@ -337,7 +340,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN:
-                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
+                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
                 e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
@@ -555,11 +558,19 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
     for (int64_t i = 0; i < m; ++i)
         if (!finite_pos(w[2 * i]) || !finite_pos(w[2 * i + 1]))
             return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: weights must be finite and > 0", (long long)i);
+    // v-independent pieces of the log-space closed forms (sweep_kernels.hip, GeoMeanLogOps)
+    std::vector<double2> ew((size_t)m), lR((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        const double eta = w[2 * i] / w[2 * i + 1]; // src/cfmms.jl:188
+        ew[(size_t)i] = make_double2(eta, 1.0 / (eta + 1.0));
+        lR[(size_t)i] = make_double2(std::log(R[2 * i]), std::log(R[2 * i + 1]));
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
     s.kind = CFMM_KIND_GEOMEAN;
     s.m = m;
-    if ((rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.w, w, (size_t)m)) ||
+    if ((rc = upload(c, &s.ew, ew.data(), (size_t)m)) || (rc = upload(c, &s.lR, lR.data(), (size_t)m)) ||
+        (rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.w, w, (size_t)m)) ||
         (rc = upload(c, &s.gamma, gamma, (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
         free_segment(s);
         return rc;

@@ -154,33 +154,51 @@ struct GeoMeanOps {
 // With c = γ·m·e·r_a (the pow-free factor of :180), l_x = log x:
 //     (c·r_b^e)^(1/(e+1))                    = exp((l_c + e·l_b) / (e+1))
 //     ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = exp((l_a + e·(l_b − l_c + l_a)) / (1+e))
-// i.e. 3 log + 2 exp per trading pool instead of 4 pow.  The exponent carries an absolute
-// rounding error of a few 1e-16·max(1, e·|l|)/(e+1), so trades agree with the reference-order
-// forms to ~1e-15 of the reserve scale (asserted at 1e-12 in tests/test_gpu_parity.py).
-struct GeoMeanLogOps : GeoMeanOps {
+// Everything that does not depend on v is prepared once at upload (cfmm_abi.hip): η = w₁/w₂,
+// 1/(η+1), log R₁, log R₂.  Direction 2 uses e = 1/η, for which the two exponents become
+// (η·l_c + l_b)/(η+1) and (η·l_a + (l_b − l_c) + l_a)/(η+1) -- no further division.  Per trading
+// pool that leaves 1 log + 2 exp + 2 divisions (c and the final /γ) instead of 4 pow + 6
+// divisions; pools inside the no-arbitrage band cost two multiplies and a compare.
+// The exponent carries an absolute rounding error of a few 1e-16·max(1, η·|l|)/(η+1), so trades
+// agree with the reference-order forms to ~1e-15 of the reserve scale (asserted at 1e-12 in
+// tests/test_gpu_parity.py); unlike r2^η in the reference, nothing here can overflow.
+struct GeoMeanLogOps {
+    struct Raw {
+        double2 R, ew, lR;
+        double g;
+        int2 ai;
+        int64_t i;
+    };
+    GeoMeanPools p;
+    __device__ __forceinline__ Raw load(int64_t i) const
+    {
+        return Raw{p.R[i], p.ew[i], p.lR[i], p.gamma[i], p.Ai[i], i};
+    }
+    __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
     {
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
-        const double eta = r.w.x / r.w.y;        // :188
-        const double ieta = 1.0 / eta;
-        const double m12 = v2 / v1, m21 = v1 / v2;
-        const double c1 = ((g * m12) * eta) * R2;    // direction 1 trades iff c1 > R1
-        const double c2 = ((g * m21) * ieta) * R1;   // direction 2 trades iff c2 > R2
-        const bool p1 = c1 > R1, p2 = c2 > R2;
+        const double eta = r.ew.x, inv = r.ew.y;      // η, 1/(η+1)
+        const double n1 = ((g * v2) * eta) * R2, d1 = v1;   // c₁ = n1/d1: direction 1 trades iff c₁ > R₁
+        const double n2 = (g * v1) * R1, d2 = v2 * eta;     // c₂ = n2/d2: direction 2 trades iff c₂ > R₂
+        const bool p1 = n1 > R1 * d1, p2 = n2 > R2 * d2;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
         if (p1 != p2) {
-            const double e = p1 ? eta : ieta, c = p1 ? c1 : c2;
+            const double lc = log((p1 ? n1 : n2) / (p1 ? d1 : d2));
             const double ra = p1 ? R2 : R1, rb = p1 ? R1 : R2;
-            const double la = log(ra), lb = log(rb), lc = log(c);
-            const double inv = 1.0 / (e + 1.0);
-            const double d = max0(exp((lc + e * lb) * inv) - rb) / g;
-            const double l = max0(ra - exp((la + e * ((lb - lc) + la)) * inv));
+            const double la = p1 ? r.lR.y : r.lR.x, lb = p1 ? r.lR.x : r.lR.y;
+            const double u = (lb - lc) + la;
+            const double A = p1 ? (lc + eta * lb) : (eta * lc + lb);
+            const double B = p1 ? (la + eta * u) : (eta * la + u);
+            const double d = max0(exp(A * inv) - rb) / g;
+            const double l = max0(ra - exp(B * inv));
             t.d1 = p1 ? d : 0.0;
             t.d2 = p1 ? 0.0 : d;
             t.l1 = p1 ? 0.0 : l;
             t.l2 = p1 ? l : 0.0;
         } else if (p1) {   // γ > 1: both directions "trade"; keep the reference's arithmetic
-            GeoMeanOps::solve(r, v1, v2, t);
+            GeoMeanOps ref{p};
+            ref.solve(GeoMeanOps::Raw{r.R, p.w[r.i], r.g, r.ai}, v1, v2, t);
         }
     }
 };
@@ -387,9 +405,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         if (sg.pools.g.reference_order) {
             sweep_body<GeoMeanOps, MAT, 1, BLOCK>(GeoMeanOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         } else {
-            GeoMeanLogOps ops;
-            ops.p = sg.pools.g;
-            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK>(ops, a, local, nblocks, blockIdx.x);
+            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         }
         break;
     default:
@@ -521,9 +537,7 @@ hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchC
 hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     if (p.reference_order) return launch_any(GeoMeanOps{p}, a, c, mat, s);
-    GeoMeanLogOps ops;
-    ops.p = p;
-    return launch_any(ops, a, c, mat, s);
+    return launch_any(GeoMeanLogOps{p}, a, c, mat, s);
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {

@@ -23,11 +23,11 @@ for w in workloads:
                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         per[c] = {k: sum(v) / len(v) for k, v in acc.items() if v}
     kernels = sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]))
-    for variant, tag in (("materialising", " true,"), ("fused", " false,")):
+    for variant, tags in (("materialising", (" true,", "<true,")), ("fused", (" false,", "<false,"))):
         tot = 0.0
         detail = {}
         for k in kernels:
-            if "sweep" not in k or tag not in k:
+            if "sweep" not in k or not any(t in k for t in tags):
                 continue
             f, wr = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
             b = (2.0 * f + wr) * 1024.0
