@@ -37,9 +37,10 @@ struct Segment {
     double* gamma = nullptr;
     int2* Ai = nullptr;
     double2* pg = nullptr;
-    int2* span = nullptr;
-    int* cur_tick = nullptr;
-    double2* ticks = nullptr;
+    int4* walk = nullptr;
+    double2* ks = nullptr;
+    double2* dt = nullptr;
+    double* rout = nullptr;
     // launch geometry (decided at upload)
     int block = kSmallBlock;
     int grid = 0;
@@ -138,7 +139,7 @@ void free_segment(Segment& s)
 {
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
     (void)hipFree(s.ew); (void)hipFree(s.lR);
-    (void)hipFree(s.pg); (void)hipFree(s.span); (void)hipFree(s.cur_tick); (void)hipFree(s.ticks);
+    (void)hipFree(s.pg); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
     s = Segment{};
 }
 
@@ -327,7 +328,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
-                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.walk, s.ks, s.dt, s.rout}; break;
                 }
             }
             e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
@@ -343,7 +344,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
-                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.span, s.cur_tick, s.ticks}, a, cfg, materialize, c->stream);
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.walk, s.ks, s.dt, s.rout}, a, cfg, materialize, c->stream);
                 break;
             }
         }
@@ -588,10 +589,13 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
         return fail(c, CFMM_ERR_INVALID_ARG, "null pool array");
     if (m > 0 && tick_off[0] != 0) return fail(c, CFMM_ERR_INVALID_ARG, "tick_off[0] must be 0");
     const int64_t T = m > 0 ? tick_off[m] : 0;
-    if (T < 0 || T > INT32_MAX) return fail(c, CFMM_ERR_UNSUPPORTED, "total tick count must fit int32");
-    std::vector<double2> pg((size_t)m), ticks((size_t)T);
-    std::vector<int2> span((size_t)m);
-    std::vector<int> cur((size_t)m);
+    if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
+    std::vector<double2> pg((size_t)m), ks, dt;
+    std::vector<double> rout;
+    std::vector<int4> walk((size_t)m);
+    ks.reserve((size_t)T + (size_t)m);
+    dt.reserve((size_t)T + (size_t)m);
+    rout.reserve((size_t)T + (size_t)m);
     for (int64_t i = 0; i < m; ++i) {
         const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
         if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
@@ -603,28 +607,67 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
         if (a < 0 || a >= c->n || b < 0 || b >= c->n)
             return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: token index out of range [0, %d)", (long long)i, c->n);
         if (a == b) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: the two token indices must differ", (long long)i);
+        const double* lt = lower_ticks + o;
+        const double* lq = liquidity + o;
         for (int64_t j = 0; j < nt; ++j) {
-            const double t = lower_ticks[o + j], L = liquidity[o + j];
-            if (!finite_pos(t)) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: price must be finite and > 0", (long long)i, (long long)j);
-            if (j > 0 && !(t < lower_ticks[o + j - 1]))
+            if (!finite_pos(lt[j])) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: price must be finite and > 0", (long long)i, (long long)j);
+            if (j > 0 && !(lt[j] < lt[j - 1]))
                 return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: lower_ticks must be strictly descending", (long long)i);
-            if (!(L >= 0.0) || !std::isfinite(L))
+            if (!(lq[j] >= 0.0) || !std::isfinite(lq[j]))
                 return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: liquidity must be finite and >= 0", (long long)i, (long long)j);
-            ticks[(size_t)(o + j)] = make_double2(t, L);
         }
+        const double cp = current_price[i];
         // src/cfmms.jl:235: searchsortedlast(lower_ticks, current_price, rev=true)
         int64_t lo = 0, hi = nt + 1;
         while (lo < hi - 1) {
             const int64_t mid = lo + ((hi - lo) >> 1);
-            if (lower_ticks[o + mid - 1] < current_price[i]) hi = mid;
+            if (lt[mid - 1] < cp) hi = mid;
             else lo = mid;
         }
-        if (lo < 1)
+        const int64_t ct = lo;
+        if (ct < 1)
             return fail(c, CFMM_ERR_INVALID_ARG,
                         "pool %lld: current_price above the first tick (the reference would index tick 0)", (long long)i);
-        pg[(size_t)i] = make_double2(current_price[i], gamma[i]);
-        span[(size_t)i] = make_int2((int)o, (int)nt);
-        cur[(size_t)i] = (int)lo;
+        // compute_at_tick(cfmm, idx), src/cfmms.jl:294-313 (idx 1-based)
+        auto at_tick = [&](int64_t idx, double& k, double& al, double& be, double& R1, double& R2) {
+            k = lq[idx - 1];
+            const double pplus = lt[idx - 1];                 // :251
+            const double pminus = idx < nt ? lt[idx] : 0.0;   // :254-259
+            al = std::sqrt(k / pplus);
+            be = std::sqrt(k * pminus);
+            const double p = idx > ct ? pplus : (idx < ct ? pminus : cp);
+            R1 = std::sqrt(k / p) - al;
+            R2 = std::sqrt(k * p) - be;
+        };
+        int4 w;
+        w.x = (int)ks.size();
+        int cnt = 0;
+        for (int64_t idx = ct; idx <= nt; ++idx) {            // get_upper_pools, :316
+            double k, al, be, R1, R2;
+            at_tick(idx, k, al, be, R1, R2);
+            if (k == 0) continue;                             // is_empty_pool, :288
+            const double s_in = R1 + al;
+            ks.push_back(make_double2(k, s_in));
+            dt.push_back(make_double2(k / be - s_in, R2 + be)); // :329, :334
+            rout.push_back(R2);
+            ++cnt;
+        }
+        w.y = cnt | ((lq[ct - 1] != 0.0 ? 1 : 0) << 30);
+        w.z = (int)ks.size();
+        cnt = 0;
+        for (int64_t idx = ct; idx >= 1; --idx) {             // flip_sides.(get_lower_pools), :317,:289
+            double k, al, be, R1, R2;
+            at_tick(idx, k, al, be, R1, R2);
+            if (k == 0) continue;
+            const double s_in = R2 + be;
+            ks.push_back(make_double2(k, s_in));
+            dt.push_back(make_double2(k / al - s_in, R1 + al));
+            rout.push_back(R1);
+            ++cnt;
+        }
+        w.w = cnt;
+        walk[(size_t)i] = w;
+        pg[(size_t)i] = make_double2(cp, gamma[i]);
     }
     HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
@@ -633,8 +676,8 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     s.n_ticks_total = T;
     int rc;
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
-        (rc = upload(c, &s.span, span.data(), (size_t)m)) || (rc = upload(c, &s.cur_tick, cur.data(), (size_t)m)) ||
-        (rc = upload(c, &s.ticks, ticks.data(), (size_t)T))) {
+        (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
+        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size()))) {
         free_segment(s);
         return rc;
     }

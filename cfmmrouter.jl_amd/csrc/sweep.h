@@ -9,7 +9,7 @@ namespace cfmm {
 
 constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
 constexpr int kBigBlock = 1024;      // 16 wavefronts: one or two fat blocks per CU, few partial rows
-constexpr int kReduceBlock = 256;
+constexpr int kReduceBlock = 1024;
 constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
 constexpr int kMaxTokens = 8192;     // v + one bin copy must fit the 160 KiB LDS of a CU
 
@@ -28,12 +28,13 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* lR;           // [m] {log R1, log R2}          prepared at upload
     int reference_order;         // 1: evaluate with pow in the reference's operation order
 };
-struct UniV3Pools {              // src/cfmms.jl:226-245, ticks in CSR form
+struct UniV3Pools {              // src/cfmms.jl:226-245, per-direction walk lists (see UniV3Ops)
     const double2* pg;           // [m] {current_price, gamma}
     const int2* Ai;              // [m]
-    const int2* span;            // [m] {tick_begin, n_ticks}
-    const int* cur_tick;         // [m] 1-based current_tick (src/cfmms.jl:235)
-    const double2* ticks;        // [T] {lower_tick, liquidity}
+    const int4* walk;            // [m] {up_begin, up_count | current_tick_nonempty << 30, lo_begin, lo_count}
+    const double2* ks;           // [W] {k, R_in + alpha_in}
+    const double2* dt;           // [W] {delta_max, R_out + beta_out}
+    const double* rout;          // [W] R_out
 };
 
 struct SweepArgs {

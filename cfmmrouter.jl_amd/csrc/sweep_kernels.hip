@@ -207,7 +207,7 @@ struct GeoMeanLogOps {
 // UniV3 / BoundedProduct -- src/cfmms.jl:294-395 (lane per pool, serial tick walk)
 // ---------------------------------------------------------------------------------------------
 // find_arb_pos(t, price) -- src/cfmms.jl:321-337, on BoundedProduct(k, a, b, R1, R2)
-__device__ __forceinline__ void find_arb_pos(double k, double a, double b, double R1, double R2,
+[[maybe_unused]] __device__ __forceinline__ void find_arb_pos(double k, double a, double b, double R1, double R2,
                                              double price, double& d, double& l)
 {
     const double s = R1 + a;
@@ -219,35 +219,23 @@ __device__ __forceinline__ void find_arb_pos(double k, double a, double b, doubl
     d = dd;
 }
 
+// Everything compute_at_tick (:294-313) derives is independent of v, so it is evaluated ONCE at
+// upload (cfmm_abi.hip, same IEEE operations, hence the same bits) into per-direction walk lists
+// that hold only the non-empty ticks, each as BoundedProduct-derived constants of find_arb_pos:
+//     ks = {k, s = R_in + α_in}    dt = {δ_max = k/β_in − s, t = R_out + β_out}    rout = R_out
+// ("in"/"out" already flipped for the lower walk, :289).  A sweep then costs one division and
+// one or two square roots per visited tick instead of six square roots and four divisions,
+// and empty ticks cost nothing.  `initial` (:352,:374) can only be true on the current tick, and
+// only if that tick is non-empty: one flag per pool.
 struct UniV3Ops {
     struct Raw {
         double2 pg;
         int2 ai;
-        int2 span;
-        int ct;
+        int4 walk;
     };
     UniV3Pools p;
-    __device__ __forceinline__ Raw load(int64_t i) const
-    {
-        return Raw{p.pg[i], p.Ai[i], p.span[i], p.cur_tick[i]};
-    }
+    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.pg[i], p.Ai[i], p.walk[i]}; }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
-
-    // compute_at_tick(cfmm, idx) -- src/cfmms.jl:294-313; idx is 1-based within the pool
-    __device__ __forceinline__ void at_tick(const Raw& r, int idx, double& k, double& a, double& b,
-                                            double& R1, double& R2) const
-    {
-        const double2* tk = p.ticks + r.span.x;
-        const double2 cur = tk[idx - 1];
-        k = cur.y;
-        const double pplus = cur.x;                                    // :251
-        const double pminus = idx < r.span.y ? tk[idx].x : 0.0;        // :254-259
-        a = sqrt(k / pplus);
-        b = sqrt(k * pminus);
-        const double pp = idx > r.ct ? pplus : (idx < r.ct ? pminus : r.pg.x);
-        R1 = sqrt(k / pp) - a;
-        R2 = sqrt(k * pp) - b;
-    }
 
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
     {
@@ -255,39 +243,33 @@ struct UniV3Ops {
         const double pr = v1 / v2;                                     // :340
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
         if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
+        const bool up = pr < g * cp;                                   // :351
+        const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
+        const int begin = up ? r.walk.x : r.walk.z;
+        const int count = up ? (r.walk.y & 0x3fffffff) : r.walk.w;
+        bool initial = (r.walk.y >> 30) & 1;
         double sd = 0.0, sl = 0.0;
-        bool initial = true;
-        if (pr < g * cp) {                                             // :351
-            const double price = pr / g;
-            for (int idx = r.ct; idx <= r.span.y; ++idx) {             // :316
-                double k, a, b, R1, R2;
-                at_tick(r, idx, k, a, b, R1, R2);
-                if (k == 0) { initial = false; continue; }             // :355-358
-                double d, l;
-                find_arb_pos(k, a, b, R1, R2, price, d, l);            // :361
-                if (!initial && (d == 0 || l == 0)) break;             // :363-365
-                sd += d;
-                sl += l;
-                initial = false;
+        for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
+            const double2 ks = p.ks[begin + j];
+            const double dd = sqrt(ks.x / price) - ks.y;               // :323
+            double d = 0.0, l = 0.0;                                   // :325-327
+            if (dd > 0) {
+                const double2 dt = p.dt[begin + j];
+                if (dd >= dt.x) {                                      // :330-332
+                    d = dt.x;
+                    l = p.rout[begin + j];
+                } else {
+                    l = dt.y - sqrt(price * ks.x);                     // :334
+                    d = dd;
+                }
             }
-            t.d1 = sd / g;                                             // :372
-            t.l2 = sl;
-        } else {
-            const double price = 1.0 / (g * pr);                       // :381
-            for (int idx = r.ct; idx >= 1; --idx) {                    // :317
-                double k, a, b, R1, R2;
-                at_tick(r, idx, k, a, b, R1, R2);
-                if (k == 0) { initial = false; continue; }
-                double d, l;
-                find_arb_pos(k, b, a, R2, R1, price, d, l);            // flip_sides :289
-                if (!initial && (d == 0 || l == 0)) break;
-                sd += d;
-                sl += l;
-                initial = false;
-            }
-            t.d2 = sd / g;                                             // :391
-            t.l1 = sl;
+            if (!initial && (d == 0 || l == 0)) break;                 // :363-365
+            sd += d;
+            sl += l;
+            initial = false;
         }
+        if (up) { t.d1 = sd / g; t.l2 = sl; }                          // :366-372
+        else { t.d2 = sd / g; t.l1 = sl; }                             // :386-391
     }
 };
 
@@ -420,9 +402,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int rows,
                                                                 int n1, double* __restrict__ out)
 {
+    // lane = (row-lane r, column c): 8 columns (one 64 B line of a row) x 128 row-lanes.  A
+    // wavefront holds 8 row-lanes x 8 columns; row-lanes are folded by a fixed shuffle tree, the
+    // 16 wavefronts by a fixed-order LDS pass.
     constexpr int kRowLanes = kReduceBlock / kReduceCols;
-    constexpr int kBatch = 8;   // independent loads in flight per lane
-    __shared__ double red[kRowLanes][kReduceCols + 1];
+    constexpr int kWaves = kReduceBlock / 64;
+    constexpr int kBatch = 4;   // independent loads in flight per lane
+    __shared__ double red[kWaves][kReduceCols];
     const int c = threadIdx.x % kReduceCols;
     const int r = threadIdx.x / kReduceCols;
     const int col = blockIdx.x * kReduceCols + c;
@@ -439,11 +425,14 @@ __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __
         }
         for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
     }
-    red[r][c] = s;
+#pragma unroll
+    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < kReduceCols) red[wave][lane] = s;
     __syncthreads();
-    if (r == 0 && col < n1) {
+    if (threadIdx.x < kReduceCols && col < n1) {
         double tsum = red[0][c];
-        for (int k = 1; k < kRowLanes; ++k) tsum += red[k][c];
+        for (int k = 1; k < kWaves; ++k) tsum += red[k][c];
         out[col] = tsum;
     }
 }
