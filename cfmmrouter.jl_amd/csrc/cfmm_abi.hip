@@ -37,6 +37,10 @@ struct Segment {
     double* gamma = nullptr;
     int2* Ai = nullptr;
     double2* pg = nullptr;
+    double2* cur_a = nullptr;
+    double2* cur_b = nullptr;
+    double* cur_c = nullptr;
+    double2* curR = nullptr;
     int4* walk = nullptr;
     double2* ks = nullptr;
     double2* dt = nullptr;
@@ -139,6 +143,7 @@ void free_segment(Segment& s)
 {
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
     (void)hipFree(s.ew); (void)hipFree(s.lR);
+    (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
     (void)hipFree(s.pg); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
     s = Segment{};
 }
@@ -328,7 +333,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
-                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.walk, s.ks, s.dt, s.rout}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout}; break;
                 }
             }
             e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
@@ -344,7 +349,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
-                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.walk, s.ks, s.dt, s.rout}, a, cfg, materialize, c->stream);
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout}, a, cfg, materialize, c->stream);
                 break;
             }
         }
@@ -590,8 +595,8 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     if (m > 0 && tick_off[0] != 0) return fail(c, CFMM_ERR_INVALID_ARG, "tick_off[0] must be 0");
     const int64_t T = m > 0 ? tick_off[m] : 0;
     if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
-    std::vector<double2> pg((size_t)m), ks, dt;
-    std::vector<double> rout;
+    std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
+    std::vector<double> rout, cur_c((size_t)m);
     std::vector<int4> walk((size_t)m);
     ks.reserve((size_t)T + (size_t)m);
     dt.reserve((size_t)T + (size_t)m);
@@ -639,10 +644,20 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
             R1 = std::sqrt(k / p) - al;
             R2 = std::sqrt(k * p) - be;
         };
+        {   // the current tick, shared by both walks
+            double k, al, be, R1, R2;
+            at_tick(ct, k, al, be, R1, R2);
+            const double sA = R1 + al, sB = R2 + be;
+            cur_a[(size_t)i] = make_double2(k, sA);
+            cur_b[(size_t)i] = make_double2(sB, k / be - sA);   // :329
+            cur_c[(size_t)i] = k / al - sB;                     // :329 on the flipped pool (:289)
+            curR[(size_t)i] = make_double2(R1, R2);
+            if (k == 0) { cur_b[(size_t)i].y = 0.0; cur_c[(size_t)i] = 0.0; } // 0/0: never read (k == 0 is skipped)
+        }
         int4 w;
         w.x = (int)ks.size();
         int cnt = 0;
-        for (int64_t idx = ct; idx <= nt; ++idx) {            // get_upper_pools, :316
+        for (int64_t idx = ct + 1; idx <= nt; ++idx) {        // get_upper_pools beyond the current tick, :316
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;                             // is_empty_pool, :288
@@ -652,10 +667,10 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
             rout.push_back(R2);
             ++cnt;
         }
-        w.y = cnt | ((lq[ct - 1] != 0.0 ? 1 : 0) << 30);
+        w.y = cnt;
         w.z = (int)ks.size();
         cnt = 0;
-        for (int64_t idx = ct; idx >= 1; --idx) {             // flip_sides.(get_lower_pools), :317,:289
+        for (int64_t idx = ct - 1; idx >= 1; --idx) {         // flip_sides.(get_lower_pools), :317,:289
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;
@@ -676,6 +691,8 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     s.n_ticks_total = T;
     int rc;
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
+        (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
+        (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
         (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
         (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size()))) {
         free_segment(s);

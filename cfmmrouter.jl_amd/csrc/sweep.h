@@ -28,10 +28,14 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* lR;           // [m] {log R1, log R2}          prepared at upload
     int reference_order;         // 1: evaluate with pow in the reference's operation order
 };
-struct UniV3Pools {              // src/cfmms.jl:226-245, per-direction walk lists (see UniV3Ops)
+struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
     const double2* pg;           // [m] {current_price, gamma}
     const int2* Ai;              // [m]
-    const int4* walk;            // [m] {up_begin, up_count | current_tick_nonempty << 30, lo_begin, lo_count}
+    const double2* cur_a;        // [m] current tick {k, R1+alpha}
+    const double2* cur_b;        // [m] current tick {R2+beta, k/beta - (R1+alpha)}
+    const double* cur_c;         // [m] current tick  k/alpha - (R2+beta)
+    const double2* curR;         // [m] current tick {R1, R2}
+    const int4* walk;            // [m] ticks beyond the current one: {up_begin, up_count, lo_begin, lo_count}
     const double2* ks;           // [W] {k, R_in + alpha_in}
     const double2* dt;           // [W] {delta_max, R_out + beta_out}
     const double* rout;          // [W] R_out

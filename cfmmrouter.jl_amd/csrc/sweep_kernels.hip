@@ -220,21 +220,30 @@ struct GeoMeanLogOps {
 }
 
 // Everything compute_at_tick (:294-313) derives is independent of v, so it is evaluated ONCE at
-// upload (cfmm_abi.hip, same IEEE operations, hence the same bits) into per-direction walk lists
-// that hold only the non-empty ticks, each as BoundedProduct-derived constants of find_arb_pos:
-//     ks = {k, s = R_in + α_in}    dt = {δ_max = k/β_in − s, t = R_out + β_out}    rout = R_out
-// ("in"/"out" already flipped for the lower walk, :289).  A sweep then costs one division and
-// one or two square roots per visited tick instead of six square roots and four divisions,
-// and empty ticks cost nothing.  `initial` (:352,:374) can only be true on the current tick, and
-// only if that tick is non-empty: one flag per pool.
+// upload (cfmm_abi.hip, same IEEE operations, hence the same bits) into the constants
+// find_arb_pos (:321-337) actually uses:
+//   * the CURRENT tick, visited first by both walks, as one record per pool
+//       cur_a = {k, sA = R₁+α}   cur_b = {sB = R₂+β, δmax↑ = k/β − sA}   cur_c = δmax↓ = k/α − sB
+//     (the flipped pool of :289 swaps sA/sB), plus curR = {R₁, R₂}, read only when the tick drains;
+//   * the ticks beyond it as per-direction walk lists of the NON-EMPTY ticks only,
+//       ks = {k, s_in}   dt = {δmax, s_out}   rout = R_out     ("in"/"out" already flipped).
+// A sweep then costs one division and one or two square roots per visited tick instead of six
+// square roots and four divisions, empty ticks cost nothing, and a pool that trades inside its
+// current tick (the common case; every BoundedProduct pool) touches only coalesced per-pool
+// streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
     struct Raw {
-        double2 pg;
+        double2 pg, ca, cb;
+        double cc;
         int2 ai;
         int4 walk;
+        int64_t i;
     };
     UniV3Pools p;
-    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.pg[i], p.Ai[i], p.walk[i]}; }
+    __device__ __forceinline__ Raw load(int64_t i) const
+    {
+        return Raw{p.pg[i], p.cur_a[i], p.cur_b[i], p.cur_c[i], p.Ai[i], p.walk[i], i};
+    }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
 
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
@@ -245,28 +254,43 @@ struct UniV3Ops {
         if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
         const bool up = pr < g * cp;                                   // :351
         const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
-        const int begin = up ? r.walk.x : r.walk.z;
-        const int count = up ? (r.walk.y & 0x3fffffff) : r.walk.w;
-        bool initial = (r.walk.y >> 30) & 1;
         double sd = 0.0, sl = 0.0;
+        // current tick: `initial` is true here unless the tick is empty (:355-358), so no break test
+        const double k0 = r.ca.x;
+        if (k0 != 0) {
+            const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
+            const double dmax = up ? r.cb.y : r.cc;
+            const double dd = sqrt(k0 / price) - s_in;                 // :323
+            if (dd > 0) {                                              // :325-327
+                if (dd >= dmax) {                                      // :330-332
+                    const double2 R = p.curR[r.i];
+                    sd = dmax;
+                    sl = up ? R.y : R.x;
+                } else {
+                    sl = s_out - sqrt(price * k0);                     // :334
+                    sd = dd;
+                }
+            }
+        }
+        const int begin = up ? r.walk.x : r.walk.z;
+        const int count = up ? r.walk.y : r.walk.w;
         for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
             const double2 ks = p.ks[begin + j];
             const double dd = sqrt(ks.x / price) - ks.y;               // :323
-            double d = 0.0, l = 0.0;                                   // :325-327
+            double d = 0.0, l = 0.0;
             if (dd > 0) {
                 const double2 dt = p.dt[begin + j];
-                if (dd >= dt.x) {                                      // :330-332
+                if (dd >= dt.x) {
                     d = dt.x;
                     l = p.rout[begin + j];
                 } else {
-                    l = dt.y - sqrt(price * ks.x);                     // :334
+                    l = dt.y - sqrt(price * ks.x);
                     d = dd;
                 }
             }
-            if (!initial && (d == 0 || l == 0)) break;                 // :363-365
+            if (d == 0 || l == 0) break;                               // :363-365 (initial is false here)
             sd += d;
             sl += l;
-            initial = false;
         }
         if (up) { t.d1 = sd / g; t.l2 = sl; }                          // :366-372
         else { t.d2 = sd / g; t.l1 = sl; }                             // :386-391
