@@ -324,43 +324,67 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
 
-    for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
-    for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
-    __syncthreads();
-
     double* my_bins = bins + (size_t)(a.copies == 1 ? 0 : wave) * a.n_pad;
     double acc = 0.0;
 
-    const int64_t tile_pools = (int64_t)kBlock * U;
-    const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-    for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {
-        const int64_t base = tile * tile_pools + tid;
-        typename Ops::Raw raw[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = base + (int64_t)u * kBlock;
-            ok[u] = i < a.m;
-            if (ok[u]) raw[u] = ops.load(i);
+    auto process = [&](const typename Ops::Raw& raw, int64_t i) {
+        const int2 tok = ops.tokens(raw);
+        const double v1 = v_s[tok.x], v2 = v_s[tok.y];   // v[r.cfmms[i].Ai]
+        Trade t;
+        ops.solve(raw, v1, v2, t);
+        if (MAT) {
+            store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
+            store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
         }
+        // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
+        acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
+        // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
+        const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
+        if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
+        if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+    };
+
+    if constexpr (U == 1) {
+        // One pool per lane per tile, register double-buffered: the next tile's pool state is
+        // requested before the current tile is solved, and the first tile's before v and the
+        // bins are staged in LDS, so no HBM round trip is exposed behind a barrier.
+        const int64_t stride = (int64_t)nblocks * kBlock;
+        int64_t i = (int64_t)bid * kBlock + tid;
+        typename Ops::Raw cur;
+        bool ok = i < a.m;
+        if (ok) cur = ops.load(i);
+        for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
+        for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
+        __syncthreads();
+        while (ok) {
+            const int64_t inext = i + stride;
+            typename Ops::Raw nxt;
+            const bool okn = inext < a.m;
+            if (okn) nxt = ops.load(inext);
+            process(cur, i);
+            cur = nxt;
+            ok = okn;
+            i = inext;
+        }
+    } else {
+        for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
+        for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
+        __syncthreads();
+        const int64_t tile_pools = (int64_t)kBlock * U;
+        const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
+        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {
+            const int64_t base = tile * tile_pools + tid;
+            typename Ops::Raw raw[U];
+            bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-            const int64_t i = base + (int64_t)u * kBlock;
-            const int2 tok = ops.tokens(raw[u]);
-            const double v1 = v_s[tok.x], v2 = v_s[tok.y];   // v[r.cfmms[i].Ai]
-            Trade t;
-            ops.solve(raw[u], v1, v2, t);
-            if (MAT) {
-                store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
-                store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = base + (int64_t)u * kBlock;
+                ok[u] = i < a.m;
+                if (ok[u]) raw[u] = ops.load(i);
             }
-            // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
-            acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
-            // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
-            const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
-            if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
-            if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) process(raw[u], base + (int64_t)u * kBlock);
         }
     }
 
