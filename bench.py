@@ -116,14 +116,24 @@ def route_leg(name, batches, n, budget_s=60.0):
         times.append(time.perf_counter() - t0)
     psi = cr.netflows(r)
     sweeps = r.info.get("funcalls")
-    r.close()
     out = {"gpu_ms": 1e3 * min(times), "evaluations": sweeps}
+    cr.route_(r, v=v0, solver="native")  # warm
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cr.route_(r, v=v0, solver="native")
+        times.append(time.perf_counter() - t0)
+    psi_native = cr.netflows(r)
+    out["gpu_native_solver_ms"] = 1e3 * min(times)
+    out["native_evaluations"] = r.info.get("funcalls")
+    r.close()
     t0 = time.perf_counter()
     ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(batches, n), v0=v0,
                            nthreads=orc.lib().oracle_max_threads())
     out["cpu_port_ms"] = 1e3 * (time.perf_counter() - t0)
     out["cpu_evaluations"] = ref["info"]["funcalls"]
     out["netflow_rel_err"] = float(np.max(np.abs(psi - ref["psi"])) / np.max(np.abs(ref["psi"])))
+    out["native_netflow_rel_err"] = float(np.max(np.abs(psi_native - ref["psi"])) / np.max(np.abs(ref["psi"])))
     return out
 
 

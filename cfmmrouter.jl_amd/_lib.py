@@ -29,6 +29,19 @@ _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _ctx = C.c_void_p
 
+OBJ_LINEAR_NONNEGATIVE, OBJ_BASKET_LIQUIDATION = 0, 1
+
+
+class RouteInfo(C.Structure):
+    _fields_ = [("f", C.c_double), ("proj_grad", C.c_double), ("iterations", C.c_int32),
+                ("evaluations", C.c_int32), ("sweeps", C.c_int32), ("status", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+FG_CALLBACK = C.CFUNCTYPE(C.c_double, C.c_void_p, _f64p, _f64p)
+
 
 class ArgumentError(ValueError):
     """The reference's ArgumentError (src/cfmms.jl:77-78, src/objectives.jl:54,97)."""
@@ -96,6 +109,10 @@ def lib():
     L.cfmm_sweep_dev.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_int]
     L.cfmm_trades_dev.argtypes = [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.cfmm_kernel_times.argtypes = [_ctx, _i64p, _f64p, _i64p, _f64p]
+    L.cfmm_route.argtypes = [_ctx, C.c_int32, _f64p, C.c_int32, _f64p, C.c_int32, C.c_double, C.c_double,
+                             C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(RouteInfo)]
+    L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
+                                       C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
     L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p, _i32p]
@@ -250,6 +267,19 @@ class Context:
         self._check(self._L.cfmm_dual_value(self._h, C.byref(acc)))
         return acc.value
 
+    def route(self, objective_kind, objective_vec, objective_index=0, v0=None, m=5, factr=1e1, pgtol=1e-5,
+              maxfun=15_000, maxiter=15_000):
+        """cfmm_route: route! entirely inside the library (own L-BFGS-B).  -> (v, psi, info dict)."""
+        ov = f64(objective_vec)
+        if ov.size != self.n_tokens:
+            raise ArgumentError("objective vector must have n_tokens entries")
+        v0a = None if v0 is None else f64(v0)
+        v, psi, info = np.empty(self.n_tokens), np.empty(self.n_tokens), RouteInfo()
+        self._check(self._L.cfmm_route(self._h, int(objective_kind), ptr(ov), int(objective_index), ptr(v0a),
+                                       int(m), float(factr), float(pgtol), int(maxfun), int(maxiter), ptr(v),
+                                       ptr(psi), C.byref(info)))
+        return v, psi, info.as_dict()
+
     def sweep_dev(self, d_v_ptr: int, d_out_ptr: int, materialize: bool):
         self._check(self._L.cfmm_sweep_dev(self._h, C.c_void_p(d_v_ptr), C.c_void_p(d_out_ptr),
                                            1 if materialize else 0))
@@ -275,3 +305,27 @@ class Context:
                                                   C.byref(u)))
             out.append({"kind": k.value, "m": m.value, "block": b.value, "grid": g.value, "unroll": u.value})
         return out
+
+
+def lbfgsb_minimize(fun, x0, bounds, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000):
+    """The library's own L-BFGS-B on a Python objective `fun(x) -> (f, g)` (host only; used by the
+    CPU tests to compare the solver with SciPy's).  bounds: list of (lo, hi) with None = unbounded."""
+    n = len(x0)
+    x = f64(np.array(x0, dtype=np.float64).copy())
+    lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+    hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+    nbd = np.array([(1 if np.isfinite(l) else 0) + (2 if np.isfinite(h) else 0) for l, h in zip(lo, hi)])
+    nbd = np.array([{0: 0, 1: 1, 3: 2, 2: 3}[int(k)] for k in nbd], dtype=np.int32)
+
+    def cb(_user, xp, gp):
+        xx = np.ctypeslib.as_array(xp, shape=(n,))
+        fval, g = fun(xx.copy())
+        np.ctypeslib.as_array(gp, shape=(n,))[:] = g
+        return float(fval)
+
+    info = RouteInfo()
+    rc = lib().cfmm_lbfgsb_minimize(n, ptr(x), ptr(lo), ptr(hi), ptr(nbd), FG_CALLBACK(cb), None, int(m),
+                                    float(factr), float(pgtol), int(maxfun), int(maxiter), C.byref(info))
+    if rc != OK:
+        raise ArgumentError(lib().cfmm_last_error(None).decode())
+    return x, info.as_dict()

@@ -1,0 +1,629 @@
+// lbfgsb.cpp -- see lbfgsb.h.  Host-only; no device code.
+#include "lbfgsb.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+namespace cfmm {
+namespace {
+
+constexpr double kEps = std::numeric_limits<double>::epsilon();
+constexpr double kInf = std::numeric_limits<double>::infinity();
+
+inline bool has_lower(int nbd) { return nbd == 1 || nbd == 2; }
+inline bool has_upper(int nbd) { return nbd == 2 || nbd == 3; }
+
+double dot(const std::vector<double>& a, const std::vector<double>& b)
+{
+    double s = 0.0;
+    for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+    return s;
+}
+
+// Dense k×k solve A·X = B (B has nrhs columns, row-major), Gaussian elimination with partial
+// pivoting.  k = 2·col <= 2·m is tiny.
+bool solve_dense(std::vector<double> A, std::vector<double>& B, int k, int nrhs)
+{
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < k; ++r)
+            if (std::fabs(A[r * k + c]) > std::fabs(A[piv * k + c])) piv = r;
+        if (A[piv * k + c] == 0.0) return false;
+        if (piv != c) {
+            for (int j = 0; j < k; ++j) std::swap(A[c * k + j], A[piv * k + j]);
+            for (int j = 0; j < nrhs; ++j) std::swap(B[c * nrhs + j], B[piv * nrhs + j]);
+        }
+        const double inv = 1.0 / A[c * k + c];
+        for (int r = 0; r < k; ++r) {
+            if (r == c) continue;
+            const double f = A[r * k + c] * inv;
+            if (f == 0.0) continue;
+            for (int j = c; j < k; ++j) A[r * k + j] -= f * A[c * k + j];
+            for (int j = 0; j < nrhs; ++j) B[r * nrhs + j] -= f * B[c * nrhs + j];
+        }
+    }
+    for (int c = 0; c < k; ++c) {
+        const double inv = 1.0 / A[c * k + c];
+        for (int j = 0; j < nrhs; ++j) B[c * nrhs + j] *= inv;
+    }
+    return true;
+}
+
+// ---- Moré–Thuente line search (the dcsrch/dcstep pair of MINPACK-2, restated) ----------------
+struct MoreThuente {
+    double ftol = 1e-3, gtol = 0.9, xtol = 0.1, stpmin = 0.0, stpmax = 0.0;
+    bool brackt = false;
+    int stage = 1;
+    double finit = 0, ginit = 0, gtest = 0, width = 0, width1 = 0;
+    double stx = 0, fx = 0, gx = 0, sty = 0, fy = 0, gy = 0, stmin = 0, stmax = 0;
+    enum Task { kEvaluate, kConverged, kWarning, kError };
+
+    Task start(double f, double g, double stp)
+    {
+        if (stp < stpmin || stp > stpmax || g >= 0.0) return kError;
+        brackt = false;
+        stage = 1;
+        finit = f;
+        ginit = g;
+        gtest = ftol * ginit;
+        width = stpmax - stpmin;
+        width1 = 2.0 * width;
+        stx = 0.0; fx = finit; gx = ginit;
+        sty = 0.0; fy = finit; gy = ginit;
+        stmin = 0.0;
+        stmax = stp + 4.0 * stp;
+        return kEvaluate;
+    }
+
+    static void step(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
+                     double fp, double dp, bool& brackt, double stpmin, double stpmax)
+    {
+        const double sgnd = dp * (dx / std::fabs(dx));
+        double stpf, stpc, stpq;
+        if (fp > fx) { // case 1: higher function value -- the minimum is bracketed
+            const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+            const double s = std::max({std::fabs(theta), std::fabs(dx), std::fabs(dp)});
+            double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+            if (stp < stx) gamma = -gamma;
+            const double p = (gamma - dx) + theta, q = ((gamma - dx) + gamma) + dp, r = p / q;
+            stpc = stx + r * (stp - stx);
+            stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+            stpf = std::fabs(stpc - stx) < std::fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+            brackt = true;
+        } else if (sgnd < 0.0) { // case 2: derivatives of opposite sign
+            const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+            const double s = std::max({std::fabs(theta), std::fabs(dx), std::fabs(dp)});
+            double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+            if (stp > stx) gamma = -gamma;
+            const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dx, r = p / q;
+            stpc = stp + r * (stx - stp);
+            stpq = stp + (dp / (dp - dx)) * (stx - stp);
+            stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
+            brackt = true;
+        } else if (std::fabs(dp) < std::fabs(dx)) { // case 3: derivative magnitude decreases
+            const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+            const double s = std::max({std::fabs(theta), std::fabs(dx), std::fabs(dp)});
+            double gamma = s * std::sqrt(std::max(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+            if (stp > stx) gamma = -gamma;
+            const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
+            if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+            else if (stp > stx) stpc = stpmax;
+            else stpc = stpmin;
+            stpq = stp + (dp / (dp - dx)) * (stx - stp);
+            if (brackt) {
+                stpf = std::fabs(stpc - stp) < std::fabs(stpq - stp) ? stpc : stpq;
+                if (stp > stx) stpf = std::min(stp + 0.66 * (sty - stp), stpf);
+                else stpf = std::max(stp + 0.66 * (sty - stp), stpf);
+            } else {
+                stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
+                stpf = std::min(stpmax, stpf);
+                stpf = std::max(stpmin, stpf);
+            }
+        } else { // case 4: derivative does not decrease
+            if (brackt) {
+                const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+                const double s = std::max({std::fabs(theta), std::fabs(dy), std::fabs(dp)});
+                double gamma = s * std::sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+                if (stp > sty) gamma = -gamma;
+                const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
+                stpc = stp + r * (sty - stp);
+                stpf = stpc;
+            } else if (stp > stx) stpf = stpmax;
+            else stpf = stpmin;
+        }
+        if (fp > fx) {
+            sty = stp; fy = fp; dy = dp;
+        } else {
+            if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+            stx = stp; fx = fp; dx = dp;
+        }
+        stp = stpf;
+    }
+
+    Task next(double f, double g, double& stp)
+    {
+        const double ftest = finit + stp * gtest;
+        if (stage == 1 && f <= ftest && g >= 0.0) stage = 2;
+        if (f <= ftest && std::fabs(g) <= gtol * (-ginit)) return kConverged;
+        if (brackt && (stp <= stmin || stp >= stmax)) return kWarning;
+        if (brackt && stmax - stmin <= xtol * stmax) return kWarning;
+        if (stp == stpmax && f <= ftest && g <= gtest) return kWarning;
+        if (stp == stpmin && (f > ftest || g >= gtest)) return kWarning;
+        if (stage == 1 && f <= fx && f > ftest) {
+            double fm = f - stp * gtest, fxm = fx - stx * gtest, fym = fy - sty * gtest;
+            double gm = g - gtest, gxm = gx - gtest, gym = gy - gtest;
+            step(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
+            fx = fxm + stx * gtest;
+            fy = fym + sty * gtest;
+            gx = gxm + gtest;
+            gy = gym + gtest;
+        } else {
+            step(stx, fx, gx, sty, fy, gy, stp, f, g, brackt, stmin, stmax);
+        }
+        if (brackt) {
+            if (std::fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+            width1 = width;
+            width = std::fabs(sty - stx);
+            stmin = std::min(stx, sty);
+            stmax = std::max(stx, sty);
+        } else {
+            stmin = stp + 1.1 * (stp - stx);
+            stmax = stp + 4.0 * (stp - stx);
+        }
+        stp = std::max(stp, stpmin);
+        stp = std::min(stp, stpmax);
+        if ((brackt && (stp <= stmin || stp >= stmax)) || (brackt && stmax - stmin <= xtol * stmax)) stp = stx;
+        return kEvaluate;
+    }
+};
+
+// ---- limited-memory matrices --------------------------------------------------------------------
+struct Memory {
+    int n = 0, m = 0, col = 0;
+    double theta = 1.0;
+    std::vector<std::vector<double>> S, Y; // col columns of length n, oldest first
+    std::vector<double> SY, SS;            // m×m, row-major, [i][j] = s_i'y_j / s_i's_j (valid for i,j < col)
+    std::vector<double> M;                 // (2col)×(2col) = K^{-1}, K = [[-D, L'],[L, θ S'S]]
+
+    void reset()
+    {
+        col = 0;
+        theta = 1.0;
+        S.clear();
+        Y.clear();
+    }
+
+    void push(const std::vector<double>& s, const std::vector<double>& y, double sy, double yy)
+    {
+        if (col == m) { // drop the oldest pair
+            S.erase(S.begin());
+            Y.erase(Y.begin());
+            for (int i = 0; i + 1 < m; ++i)
+                for (int j = 0; j + 1 < m; ++j) {
+                    SY[i * m + j] = SY[(i + 1) * m + j + 1];
+                    SS[i * m + j] = SS[(i + 1) * m + j + 1];
+                }
+            --col;
+        }
+        S.push_back(s);
+        Y.push_back(y);
+        const int k = col;
+        for (int i = 0; i <= k; ++i) {
+            SY[i * m + k] = dot(S[i], y);
+            SY[k * m + i] = dot(s, Y[i]);
+            SS[i * m + k] = SS[k * m + i] = dot(S[i], s);
+        }
+        SY[k * m + k] = sy;
+        ++col;
+        theta = yy / sy;
+        form_M();
+    }
+
+    bool form_M()
+    {
+        const int k = 2 * col;
+        std::vector<double> K((size_t)k * k, 0.0);
+        for (int i = 0; i < col; ++i) {
+            K[i * k + i] = -SY[i * m + i]; // -D
+            for (int j = 0; j < col; ++j) {
+                if (i > j) { // L_ij = s_i'y_j, i > j
+                    K[(col + i) * k + j] = SY[i * m + j];
+                    K[j * k + (col + i)] = SY[i * m + j];
+                }
+                K[(col + i) * k + (col + j)] = theta * SS[i * m + j];
+            }
+        }
+        M.assign((size_t)k * k, 0.0);
+        for (int i = 0; i < k; ++i) M[i * k + i] = 1.0;
+        return solve_dense(K, M, k, k);
+    }
+
+    // row b of W = [Y θS]
+    void w_row(int b, std::vector<double>& w) const
+    {
+        for (int j = 0; j < col; ++j) {
+            w[j] = Y[j][b];
+            w[col + j] = theta * S[j][b];
+        }
+    }
+    void M_times(const std::vector<double>& v, std::vector<double>& out) const
+    {
+        const int k = 2 * col;
+        for (int i = 0; i < k; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < k; ++j) s += M[i * k + j] * v[j];
+            out[i] = s;
+        }
+    }
+};
+
+double projected_gradient_norm(int n, const double* x, const double* g, const double* l, const double* u,
+                               const int* nbd)
+{
+    double nrm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double gi = g[i];
+        if (nbd[i] != 0) {
+            if (gi < 0.0) {
+                if (has_upper(nbd[i])) gi = std::max(x[i] - u[i], gi);
+            } else {
+                if (has_lower(nbd[i])) gi = std::min(x[i] - l[i], gi);
+            }
+        }
+        nrm = std::max(nrm, std::fabs(gi));
+    }
+    return nrm;
+}
+
+} // namespace
+
+LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double* upper, const int* nbd_in,
+                             const LbfgsbFn& fg, const LbfgsbOptions& opt)
+{
+    LbfgsbResult res;
+    const int m = std::max(1, opt.m);
+    std::vector<int> nbd(nbd_in, nbd_in + n);
+    std::vector<double> l(n), u(n);
+    bool constrained = false, boxed = true;
+    for (int i = 0; i < n; ++i) {
+        l[i] = lower ? lower[i] : -kInf;
+        u[i] = upper ? upper[i] : kInf;
+        // infinite bounds are no bounds (the reference passes nbd = 2 with u = Inf, src/router.jl:68-70)
+        const bool hl = has_lower(nbd[i]) && std::isfinite(l[i]);
+        const bool hu = has_upper(nbd[i]) && std::isfinite(u[i]);
+        nbd[i] = hl ? (hu ? 2 : 1) : (hu ? 3 : 0);
+        if (nbd[i] != 0) constrained = true;
+        if (nbd[i] != 2) boxed = false;
+        // project the starting point into the box
+        if (hl && x[i] < l[i]) x[i] = l[i];
+        if (hu && x[i] > u[i]) x[i] = u[i];
+    }
+
+    Memory mem;
+    mem.n = n;
+    mem.m = m;
+    mem.SY.assign((size_t)m * m, 0.0);
+    mem.SS.assign((size_t)m * m, 0.0);
+
+    std::vector<double> g(n), g_old(n), x_old(n), xcp(n), z(n), d(n), t(n), s(n), y(n);
+    std::vector<double> p, c, wb, v1, v2, Mc;
+    std::vector<int> order, fixed(n);
+
+    auto evaluate = [&](double* xx, double* gg) -> double {
+        ++res.evaluations;
+        return fg(xx, gg);
+    };
+
+    double f = evaluate(x, g.data());
+    if (!std::isfinite(f)) {
+        res.status = 5;
+        res.message = "ERROR: non-finite objective at the (projected) starting point";
+        res.f = f;
+        return res;
+    }
+    double pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+    if (pg <= opt.pgtol) {
+        res.f = f;
+        res.proj_grad = pg;
+        res.status = 0;
+        res.message = "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL";
+        return res;
+    }
+
+    int iter = 0;
+    for (;;) {
+        const int col = mem.col;
+        const int k2 = 2 * col;
+        const double theta = mem.theta;
+        p.assign(k2, 0.0);
+        c.assign(k2, 0.0);
+        wb.assign(k2, 0.0);
+        v1.assign(k2, 0.0);
+        v2.assign(k2, 0.0);
+        Mc.assign(k2, 0.0);
+
+        // ---------------- generalized Cauchy point (BLNZ95, Algorithm CP) -------------------------
+        if (!constrained && col > 0) {
+            for (int i = 0; i < n; ++i) { xcp[i] = x[i]; fixed[i] = 0; }
+        } else {
+            order.clear();
+            double dtd = 0.0;
+            int moving = 0;
+            for (int i = 0; i < n; ++i) {
+                double ti = kInf;
+                if (g[i] < 0.0 && has_upper(nbd[i])) ti = (x[i] - u[i]) / g[i];
+                else if (g[i] > 0.0 && has_lower(nbd[i])) ti = (x[i] - l[i]) / g[i];
+                t[i] = ti;
+                fixed[i] = 0;
+                if (ti <= 0.0) { // at its bound with the gradient pushing outward
+                    d[i] = 0.0;
+                    fixed[i] = 1;
+                } else {
+                    d[i] = -g[i];
+                    dtd += d[i] * d[i];
+                    if (d[i] != 0.0) ++moving;
+                    if (std::isfinite(ti)) order.push_back(i);
+                }
+                xcp[i] = x[i];
+            }
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a] < t[b]; });
+            for (int j = 0; j < col; ++j) {
+                p[j] = dot(mem.Y[j], d);
+                p[col + j] = theta * dot(mem.S[j], d);
+            }
+            double fp = -dtd;
+            double fpp = -theta * fp;
+            if (col > 0) {
+                mem.M_times(p, v1);
+                for (int j = 0; j < k2; ++j) fpp -= p[j] * v1[j];
+            }
+            const double fpp_org = fpp;
+            double dt_min = fpp > 0.0 ? -fp / fpp : 0.0;
+            double t_old = 0.0;
+            size_t next = 0;
+            bool all_fixed = moving == 0;
+            while (!all_fixed && next < order.size()) {
+                const int b = order[next];
+                const double tb = t[b];
+                const double dt = tb - t_old;
+                if (dt_min < dt) break;
+                // variable b reaches its bound
+                ++next;
+                const double gb = g[b];
+                xcp[b] = d[b] > 0.0 ? u[b] : l[b];
+                const double zb = xcp[b] - x[b];
+                d[b] = 0.0;
+                fixed[b] = 1;
+                for (int j = 0; j < k2; ++j) c[j] += dt * p[j];
+                fp += dt * fpp + gb * gb + theta * gb * zb;
+                fpp -= theta * gb * gb;
+                if (col > 0) {
+                    mem.w_row(b, wb);
+                    mem.M_times(c, v1);       // M c
+                    mem.M_times(p, v2);       // M p
+                    double wMc = 0, wMp = 0, wMw = 0;
+                    for (int j = 0; j < k2; ++j) { wMc += wb[j] * v1[j]; wMp += wb[j] * v2[j]; }
+                    mem.M_times(wb, v1);
+                    for (int j = 0; j < k2; ++j) wMw += wb[j] * v1[j];
+                    fp -= gb * wMc;
+                    fpp -= 2.0 * gb * wMp + gb * gb * wMw;
+                    for (int j = 0; j < k2; ++j) p[j] += gb * wb[j];
+                }
+                fpp = std::max(kEps * fpp_org, fpp);
+                dt_min = -fp / fpp;
+                t_old = tb;
+                all_fixed = --moving == 0;
+            }
+            if (!all_fixed) {
+                dt_min = std::max(dt_min, 0.0);
+                t_old += dt_min;
+                for (int i = 0; i < n; ++i)
+                    if (d[i] != 0.0) xcp[i] = x[i] + t_old * d[i];
+                for (int j = 0; j < k2; ++j) c[j] += dt_min * p[j];
+            }
+        }
+
+        // ---------------- subspace minimization (BLNZ95 §5.1 direct primal + MN11 projection) -----
+        for (int i = 0; i < n; ++i) z[i] = xcp[i];
+        std::vector<int> free_idx;
+        for (int i = 0; i < n; ++i)
+            if (!fixed[i]) free_idx.push_back(i);
+        if (col > 0 && !free_idx.empty()) {
+            const int nf = (int)free_idx.size();
+            // r = Z'(g + θ(xcp − x) − W M c)
+            std::vector<double> r(nf);
+            mem.M_times(c, Mc);
+            for (int a = 0; a < nf; ++a) {
+                const int i = free_idx[a];
+                double wmc = 0.0;
+                for (int j = 0; j < col; ++j) wmc += mem.Y[j][i] * Mc[j] + theta * mem.S[j][i] * Mc[col + j];
+                r[a] = g[i] + theta * (xcp[i] - x[i]) - wmc;
+            }
+            // v = M W'Z r ;  N = I − (1/θ) M (W'Z Z'W) ;  v = N^{-1} v
+            std::vector<double> wzr(k2, 0.0), WZ((size_t)k2 * k2, 0.0);
+            for (int a = 0; a < nf; ++a) {
+                const int i = free_idx[a];
+                for (int j = 0; j < col; ++j) {
+                    wb[j] = mem.Y[j][i];
+                    wb[col + j] = theta * mem.S[j][i];
+                }
+                for (int j = 0; j < k2; ++j) {
+                    wzr[j] += wb[j] * r[a];
+                    for (int q = 0; q < k2; ++q) WZ[j * k2 + q] += wb[j] * wb[q];
+                }
+            }
+            std::vector<double> v(k2), N((size_t)k2 * k2, 0.0);
+            mem.M_times(wzr, v);
+            for (int i = 0; i < k2; ++i)
+                for (int j = 0; j < k2; ++j) {
+                    double sum = 0.0;
+                    for (int q = 0; q < k2; ++q) sum += mem.M[i * k2 + q] * WZ[q * k2 + j];
+                    N[i * k2 + j] = (i == j ? 1.0 : 0.0) - sum / theta;
+                }
+            if (solve_dense(N, v, k2, 1)) {
+                // d̂ = −(1/θ) r − (1/θ²) Z'W v
+                std::vector<double> du(nf);
+                for (int a = 0; a < nf; ++a) {
+                    const int i = free_idx[a];
+                    double wv = 0.0;
+                    for (int j = 0; j < col; ++j) wv += mem.Y[j][i] * v[j] + theta * mem.S[j][i] * v[col + j];
+                    du[a] = -r[a] / theta - wv / (theta * theta);
+                }
+                // MN11: project the subspace minimizer onto the box; keep it if it is a descent
+                // direction for the objective, otherwise truncate the step (v2.1 behaviour).
+                double dd_p = 0.0;
+                for (int a = 0; a < nf; ++a) {
+                    const int i = free_idx[a];
+                    double xi = xcp[i] + du[a];
+                    if (has_lower(nbd[i])) xi = std::max(xi, l[i]);
+                    if (has_upper(nbd[i])) xi = std::min(xi, u[i]);
+                    z[i] = xi;
+                }
+                for (int i = 0; i < n; ++i) dd_p += (z[i] - x[i]) * g[i];
+                if (dd_p > 0.0) {
+                    double alpha = 1.0;
+                    for (int a = 0; a < nf; ++a) {
+                        const int i = free_idx[a];
+                        const double dk = du[a];
+                        if (dk < 0.0 && has_lower(nbd[i])) {
+                            const double room = l[i] - xcp[i];
+                            if (room >= 0.0) alpha = 0.0;
+                            else if (dk * alpha < room) alpha = room / dk;
+                        } else if (dk > 0.0 && has_upper(nbd[i])) {
+                            const double room = u[i] - xcp[i];
+                            if (room <= 0.0) alpha = 0.0;
+                            else if (dk * alpha > room) alpha = room / dk;
+                        }
+                    }
+                    for (int i = 0; i < n; ++i) z[i] = xcp[i];
+                    for (int a = 0; a < nf; ++a) z[free_idx[a]] = xcp[free_idx[a]] + alpha * du[a];
+                }
+            }
+        }
+
+        // ---------------- line search along d = z − x -------------------------------------------
+        double dnorm2 = 0.0, gd = 0.0;
+        for (int i = 0; i < n; ++i) {
+            d[i] = z[i] - x[i];
+            dnorm2 += d[i] * d[i];
+            gd += g[i] * d[i];
+        }
+        bool ls_failed = false;
+        if (!(gd < 0.0)) {
+            ls_failed = true; // not a descent direction
+        }
+        double stp = 1.0, f_old = f;
+        if (!ls_failed) {
+            double stpmx = 1e10;
+            if (constrained) {
+                if (iter == 0) stpmx = 1.0;
+                else {
+                    for (int i = 0; i < n; ++i) {
+                        const double a1 = d[i];
+                        if (nbd[i] == 0) continue;
+                        if (a1 < 0.0 && has_lower(nbd[i])) {
+                            const double a2 = l[i] - x[i];
+                            if (a2 >= 0.0) stpmx = 0.0;
+                            else if (a1 * stpmx < a2) stpmx = a2 / a1;
+                        } else if (a1 > 0.0 && has_upper(nbd[i])) {
+                            const double a2 = u[i] - x[i];
+                            if (a2 <= 0.0) stpmx = 0.0;
+                            else if (a1 * stpmx > a2) stpmx = a2 / a1;
+                        }
+                    }
+                }
+            }
+            stp = (iter == 0 && !boxed) ? std::min(1.0 / std::sqrt(dnorm2), stpmx) : std::min(1.0, stpmx);
+            x_old.assign(x, x + n);
+            g_old = g;
+            MoreThuente ls;
+            ls.stpmax = stpmx;
+            auto task = ls.start(f, gd, stp);
+            int nfev = 0;
+            if (task == MoreThuente::kError) ls_failed = true;
+            while (!ls_failed && task == MoreThuente::kEvaluate) {
+                if (stp == 1.0) for (int i = 0; i < n; ++i) x[i] = z[i];
+                else for (int i = 0; i < n; ++i) x[i] = stp * d[i] + x_old[i];
+                const double fnew = evaluate(x, g.data());
+                ++nfev;
+                if (!std::isfinite(fnew)) {
+                    res.status = 5;
+                    res.message = "ERROR: non-finite objective inside the feasible box";
+                    for (int i = 0; i < n; ++i) x[i] = x_old[i];
+                    res.f = f_old;
+                    res.iterations = iter;
+                    return res;
+                }
+                double gdn = 0.0;
+                for (int i = 0; i < n; ++i) gdn += g[i] * d[i];
+                f = fnew;
+                task = ls.next(f, gdn, stp);
+                if (task == MoreThuente::kEvaluate &&
+                    (nfev >= opt.max_linesearch || res.evaluations >= opt.maxfun)) {
+                    ls_failed = res.evaluations < opt.maxfun;
+                    break;
+                }
+            }
+            if (!ls_failed && task == MoreThuente::kError) ls_failed = true;
+            if (ls_failed) { // restore the last iterate
+                for (int i = 0; i < n; ++i) x[i] = x_old[i];
+                g = g_old;
+                f = f_old;
+            }
+        }
+        if (ls_failed) {
+            if (mem.col == 0) {
+                res.status = 4;
+                res.message = "ABNORMAL_TERMINATION_IN_LNSRCH";
+                break;
+            }
+            mem.reset(); // refresh the limited-memory model and retry from the same point
+            continue;
+        }
+        ++iter;
+
+        // ---------------- termination tests ------------------------------------------------------
+        pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+        if (pg <= opt.pgtol) {
+            res.status = 0;
+            res.message = "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL";
+            break;
+        }
+        const double scale = std::max({std::fabs(f_old), std::fabs(f), 1.0});
+        if (f_old - f <= opt.factr * kEps * scale) {
+            res.status = 1;
+            res.message = "CONVERGENCE: RELATIVE REDUCTION OF F <= FACTR*EPSMCH";
+            break;
+        }
+        if (iter >= opt.maxiter) {
+            res.status = 2;
+            res.message = "STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT";
+            break;
+        }
+        if (res.evaluations >= opt.maxfun) {
+            res.status = 3;
+            res.message = "STOP: TOTAL NO. OF F,G EVALUATIONS EXCEEDS LIMIT";
+            break;
+        }
+
+        // ---------------- limited-memory update --------------------------------------------------
+        double sy = 0.0, yy = 0.0, sg_old = 0.0;
+        for (int i = 0; i < n; ++i) {
+            s[i] = x[i] - x_old[i];
+            y[i] = g[i] - g_old[i];
+            sy += s[i] * y[i];
+            yy += y[i] * y[i];
+            sg_old += s[i] * g_old[i];
+        }
+        if (sy > kEps * (-sg_old)) mem.push(s, y, sy, yy); // else: curvature too small, skip
+    }
+
+    res.f = f;
+    res.iterations = iter;
+    res.proj_grad = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+    return res;
+}
+
+} // namespace cfmm

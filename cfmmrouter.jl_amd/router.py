@@ -164,11 +164,22 @@ def find_arb_(r: Router, v):
     return None
 
 
-def route_(r: Router, v=None, verbose=False, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000):
+def route_(r: Router, v=None, verbose=False, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000,
+           solver="scipy"):
     """route!(r; v, verbose, m, factr, pgtol, maxfun, maxiter) -- src/router.jl:58-108.
 
     Overwrites r.Δs, r.Λs and r.v.  The dual function g(ν) = f(ν) + Σᵢ arbᵢ(Aᵢᵀν) is minimised
-    with L-BFGS-B over the objective's box; each evaluation is one device sweep."""
+    with L-BFGS-B over the objective's box; each evaluation is one device sweep.
+
+    solver="scipy"  (default): SciPy's translation of the Fortran L-BFGS-B 3.0 the reference calls
+                    through LBFGSB.jl drives the loop from Python, one C-ABI call per evaluation.
+    solver="native": the library's own L-BFGS-B (csrc/lbfgsb.cpp).  On a single-GPU router the whole
+                    of route! then runs inside ONE C-ABI call (cfmm_route): no interpreter between
+                    two device sweeps."""
+    if solver == "native":
+        return _route_native(r, v, m, factr, pgtol, maxfun, maxiter)
+    if solver != "scipy":
+        raise ArgumentError("solver must be 'scipy' or 'native'")
     from scipy.optimize import fmin_l_bfgs_b
 
     n = r.v.size
@@ -202,6 +213,53 @@ def route_(r: Router, v=None, verbose=False, m=5, factr=1e1, pgtol=1e-5, maxfun=
     r.v[:] = x  # :106
     r.info = {"f": fmin, **{k: info[k] for k in ("warnflag", "task", "funcalls", "nit") if k in info}}
     find_arb_(r, r.v)  # :107
+    return None
+
+
+def _route_native(r: Router, v, m, factr, pgtol, maxfun, maxiter):
+    from ._lib import OBJ_BASKET_LIQUIDATION, OBJ_LINEAR_NONNEGATIVE, lbfgsb_minimize
+
+    n = r.v.size
+    obj = r.objective
+    if isinstance(r._backend, DeviceBackend):   # everything in one library call
+        if isinstance(obj, _obj.LinearNonnegative):
+            kind, vec, idx = OBJ_LINEAR_NONNEGATIVE, obj.c, 0
+        elif isinstance(obj, _obj.BasketLiquidation):
+            kind, vec, idx = OBJ_BASKET_LIQUIDATION, obj.Δin, obj.i - 1
+        else:
+            raise ArgumentError("solver='native' knows LinearNonnegative and BasketLiquidation objectives")
+        vout, psi, info = r._backend.ctx.route(kind, vec, idx, v0=v, m=m, factr=factr, pgtol=pgtol,
+                                               maxfun=maxfun, maxiter=maxiter)
+        r.v[:] = vout
+        r._psi, r._acc = psi, r._backend.ctx.dual_value()
+        r._trades_stale = True
+        r.n_sweeps += info["sweeps"]
+        r.info = {"f": info["f"], "funcalls": info["evaluations"], "nit": info["iterations"],
+                  "warnflag": 0 if info["status"] in (0, 1) else 2, "task": info["status"], "solver": "native"}
+        return None
+    # any other backend (sharded, test-injected): same solver, Python callback per evaluation
+    r.v[:] = np.ones(n) / n if v is None else v
+    lo, up = _obj.lower_limit(r.objective), _obj.upper_limit(r.objective)
+    bounds = [(lo[j], None if math.isinf(up[j]) else up[j]) for j in range(n)]
+
+    def sweep(x):
+        r._psi, r._acc = r._backend.eval(x)
+        r.n_sweeps += 1
+
+    def fg(x):
+        if not np.all(x == r.v):
+            sweep(x)
+            r.v[:] = x
+        G = np.zeros(n)
+        _obj.grad_(G, r.objective, x)
+        return _obj.f(r.objective, x) + r._acc, G + r._psi
+
+    sweep(r.v)
+    x, info = lbfgsb_minimize(fg, r.v.copy(), bounds, m=m, factr=factr, pgtol=pgtol, maxfun=maxfun, maxiter=maxiter)
+    r.v[:] = x
+    r.info = {"f": info["f"], "funcalls": info["evaluations"], "nit": info["iterations"],
+              "warnflag": 0 if info["status"] in (0, 1) else 2, "task": info["status"], "solver": "native"}
+    find_arb_(r, r.v)
     return None
 
 

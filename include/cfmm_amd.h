@@ -137,6 +137,38 @@ int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lamb
 int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
                       int64_t* reduce_launches, double* reduce_ms);
 
+/* ---- route! without an interpreter in the loop ----------------------- */
+
+#define CFMM_OBJ_LINEAR_NONNEGATIVE 0 /* LinearNonnegative(c)      src/objectives.jl:51-79 */
+#define CFMM_OBJ_BASKET_LIQUIDATION 1 /* BasketLiquidation(i, Din) src/objectives.jl:92-129 */
+
+typedef struct cfmm_route_info {
+    double f;            /* dual value g(v*) */
+    double proj_grad;    /* max-norm of the projected gradient at v* */
+    int32_t iterations;  /* L-BFGS-B iterations */
+    int32_t evaluations; /* fn/g! evaluations == device sweeps inside the solver */
+    int32_t sweeps;      /* all device sweeps incl. prologue and epilogue (src/router.jl:104,107) */
+    int32_t status;      /* 0 pgtol, 1 factr, 2 maxiter, 3 maxfun, 4 line search, 5 non-finite f */
+} cfmm_route_info;
+
+/* route!(r; v, m, factr, pgtol, maxfun, maxiter) -- src/router.jl:58-108, with the external
+ * LBFGSB.jl solver (src/router.jl:60,105) replaced by this library's own L-BFGS-B
+ * (csrc/lbfgsb.cpp, written from the published algorithm).  objective_vec is `c`
+ * (LinearNonnegative) or `Din` (BasketLiquidation, objective_index = 0-based output token);
+ * v0 may be NULL (the reference's default ones(n)/n, :62).  On return v_out[n] = r.v,
+ * psi_out[n] = netflows(r), trades are materialised at v* (cfmm_get_trades).  Pass
+ * maxfun = maxiter = 15000, m = 5, factr = 1e1, pgtol = 1e-5 for the reference's defaults. */
+int cfmm_route(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_vec, int32_t objective_index,
+               const double* v0, int32_t m, double factr, double pgtol, int32_t maxfun, int32_t maxiter,
+               double* v_out, double* psi_out, cfmm_route_info* info);
+
+/* The solver alone on a caller-supplied objective (used by the CPU tests to compare it with
+ * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g. */
+typedef double (*cfmm_fg_callback)(void* user, const double* x, double* g);
+int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
+                         cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
+                         int32_t maxiter, cfmm_route_info* info);
+
 /* Number of segments and their description (kind, pool count, launch geometry). */
 int32_t cfmm_segment_count(const cfmm_ctx* ctx);
 int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* block,

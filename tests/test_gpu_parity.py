@@ -290,6 +290,29 @@ def test_route_basket_liquidation_parity():
     r.close()
 
 
+@pytest.mark.parametrize("kind", ["arb", "basket", "mixed"])
+def test_route_native_solver_one_call(kind):
+    """cfmm_route: the whole of route! inside the library (own L-BFGS-B) vs the CPU restatement."""
+    n = 48
+    if kind == "mixed":
+        market = [synth.product_pools(20_000, n, seed=3), synth.geomean_pools(10_000, n, seed=4),
+                  synth.bounded_product_pools(10_000, n, seed=5)]
+    else:
+        market = [synth.product_pools(30_000, n, seed=9)]
+    obj = cr.BasketLiquidation(2, synth.basket(n, seed=2)) if kind == "basket" else \
+        cr.LinearNonnegative(synth.linear_prices(n, seed=3))
+    v0 = None if kind == "basket" else np.ones(n)
+    r = cr.Router(obj, market, n)
+    cr.route_(r, v=v0, solver="native")
+    ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(r._batches, n), v0=v0)
+    assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
+    assert abs(r.info["f"] - ref["f"]) <= 1e-9 * max(1.0, abs(ref["f"]))
+    assert np.all(r.v >= cr.lower_limit(obj) - 1e-12)
+    D, L = r.Δs, r.Λs                      # trades were materialised at v* by the same call
+    assert D.shape == (sum(len(b) for b in market), 2) and np.all(D >= 0) and np.all(L >= 0)
+    r.close()
+
+
 # ---- BASELINE-size properties (no oracle at this size inside the timed budget) ---------------------------
 
 def test_full_size_properties():

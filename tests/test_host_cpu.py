@@ -195,6 +195,17 @@ class TestRouteLoopOnOracleBackend:
         np.testing.assert_array_equal(cr.netflows(r), ref["psi"])
         assert r.n_sweeps == ref["n_sweeps"]
 
+    def test_native_solver_on_injected_backend(self):
+        n, m = 16, 1500
+        b = synth.product_pools(m, n, seed=8)
+        obj = cr.BasketLiquidation(1, synth.basket(n, seed=8))
+        r1, r2 = oracle_router(obj, b, n), oracle_router(obj, b, n)
+        cr.route_(r1)
+        cr.route_(r2, solver="native")
+        assert rel_to_max(cr.netflows(r2), cr.netflows(r1)) <= 1e-6
+        np.testing.assert_allclose(r2.v, r1.v, rtol=1e-6)
+        check_primal_feasibility(r2, arb=False)
+
     def test_interleaved_families_keep_router_order(self):
         n = 6
         bp, bg = synth.product_pools(5, n, 1), synth.geomean_pools(4, n, 2)
