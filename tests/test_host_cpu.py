@@ -243,3 +243,24 @@ class TestSynth:
         parts = [b.slice(0, 20), b.slice(20, 50)]
         assert np.array_equal(np.concatenate([p.lower_ticks for p in parts]), b.lower_ticks)
         assert parts[1].tick_off[0] == 0 and len(parts[1]) == 30
+
+
+def test_market_file_round_trip(tmp_path):
+    from cfmmrouter_amd import poolfile
+    n = 12
+    batches = [synth.product_pools(30, n, 1), synth.geomean_pools(20, n, 2), synth.univ3_pools(10, n, 4, 3)]
+    for obj, v0 in ((cr.LinearNonnegative(synth.linear_prices(n, 4)), np.ones(n)),
+                    (cr.BasketLiquidation(2, synth.basket(n, 5)), None)):
+        p = str(tmp_path / "m.bin")
+        poolfile.save_market(p, batches, n, obj, v0)
+        b2, n2, obj2, v02 = poolfile.load_market(p)
+        assert n2 == n and type(obj2) is type(obj) and (v0 is None) == (v02 is None)
+        for a, b in zip(batches, b2):
+            assert a.kind == b.kind
+            np.testing.assert_array_equal(a.γ, b.γ)
+            np.testing.assert_array_equal(a.Ai, b.Ai)
+            if a.kind != 2:
+                np.testing.assert_array_equal(a.R, b.R)
+            else:
+                np.testing.assert_array_equal(a.lower_ticks, b.lower_ticks)
+                np.testing.assert_array_equal(a.tick_off, b.tick_off)
