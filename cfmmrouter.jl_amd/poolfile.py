@@ -1,4 +1,4 @@
-"""Flat little-endian market files, so that every implementation (this package, the CPU oracle,
+"""Flat little-endian market files, so that every implementation (this package, the CPU checker in tests,
 and the reference itself through bench/reference.jl) reads IDENTICAL pool bits (SURVEY §7.1:
 Julia's `rand` stream cannot be reproduced outside Julia).
 
