@@ -194,20 +194,18 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
     }
 }
 
+bool global_bins(const cfmm_ctx* c) { return c->n > kMaxLdsTokens; }
+int row_width(const cfmm_ctx* c) { return global_bins(c) ? 1 : c->n + 1; }
+
 int bin_copies(const cfmm_ctx* c, int block)
 {
+    if (global_bins(c)) return 1;
     const int waves = block / 64;
     if (c->opt_bin_copies == 1) return 1;
     const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block);
     if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
     // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
     return per_wave <= (block == kBigBlock ? 80 : 64) * 1024 ? waves : 1;
-}
-
-size_t max_lds(const cfmm_ctx* c)
-{
-    return std::max(sweep_lds_bytes(c->n_pad, bin_copies(c, kSmallBlock), kSmallBlock),
-                    sweep_lds_bytes(c->n_pad, bin_copies(c, kBigBlock), kBigBlock));
 }
 
 int ensure_geometry(cfmm_ctx* c)
@@ -267,7 +265,7 @@ int ensure_geometry(cfmm_ctx* c)
         (void)hipFree(c->d_partials);
         c->d_partials = nullptr;
         c->rows_cap = 0;
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials), (size_t)rows * (c->n + 1) * sizeof(double)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials), (size_t)rows * row_width(c) * sizeof(double)));
         c->rows_cap = rows;
     }
     if (trades > c->trade_cap) {
@@ -300,7 +298,9 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
     const bool timed = c->opt_time_kernels != 0;
+    const bool gb = global_bins(c);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (gb) HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)c->n * sizeof(double), c->stream));
     for (const Group& g : c->groups) {
         SweepArgs a;
         a.v = d_v;
@@ -309,9 +309,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.copies = bin_copies(c, g.block);
         a.m = 0;
         a.Delta = a.Lambda = nullptr;
-        a.partials = c->d_partials + (size_t)g.row_off * (c->n + 1);
+        a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
+        a.gbins = gb ? d_out : nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
-        const size_t lds = sweep_lds_bytes(c->n_pad, a.copies, g.block);
+        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) {
             ea = take_event(c);
@@ -367,7 +368,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (ra && rb) HIP_TRY(c, hipEventRecord(ra, c->stream));
     }
     if (c->rows_total > 0) {
-        hipError_t e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
+        hipError_t e = gb ? launch_reduce(c->d_partials, (int)c->rows_total, 1, d_out + c->n, c->stream)
+                          : launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
@@ -421,8 +423,8 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     if (!out) return fail(nullptr, CFMM_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
     if (n_tokens < 1) return fail(nullptr, CFMM_ERR_INVALID_ARG, "n_tokens must be >= 1");
-    if (n_tokens > kMaxTokens)
-        return fail(nullptr, CFMM_ERR_UNSUPPORTED, "n_tokens %d exceeds the LDS-resident limit %d", n_tokens, kMaxTokens);
+    if (n_tokens > (1 << 26))
+        return fail(nullptr, CFMM_ERR_UNSUPPORTED, "n_tokens %d exceeds the supported maximum %d", n_tokens, 1 << 26);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -459,7 +461,9 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double), hipHostMallocDefault));
-    HIP_TRY_C(prepare_kernels(max_lds(c)));
+    // the dynamic-LDS ceiling is a per-function, process-wide attribute: always raise it to the
+    // full 160 KiB so that contexts with different n_tokens cannot shrink each other's limit
+    HIP_TRY_C(prepare_kernels(160 * 1024));
 #undef HIP_TRY_C
     *out = c;
     return CFMM_OK;
@@ -520,10 +524,6 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
     if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == 2))
         return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 (shared) or 2 (per wavefront)");
     *slot = value;
-    if (slot == &c->opt_bin_copies) {
-        hipError_t e = prepare_kernels(max_lds(c));
-        if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "prepare_kernels: %s", hipGetErrorString(e));
-    }
     if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments)
         c->geometry_dirty = true;
     return CFMM_OK;

@@ -11,7 +11,8 @@ constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
 constexpr int kBigBlock = 1024;      // 16 wavefronts: one or two fat blocks per CU, few partial rows
 constexpr int kReduceBlock = 1024;
 constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
-constexpr int kMaxTokens = 8192;     // v + one bin copy must fit the 160 KiB LDS of a CU
+constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 KiB LDS of a CU;
+                                     // larger markets use global bins (sweep_body<..., GBINS=true>)
 
 // SoA-of-pairs pool stores, one struct per pool family.  All pointers are device pointers.
 struct ProductPools {            // src/cfmms.jl:101-111
@@ -49,7 +50,8 @@ struct SweepArgs {
     int64_t m;                   // pools in this segment
     double2* Delta;              // [m] segment base, may be null when !materialize
     double2* Lambda;
-    double* partials;            // [grid][n+1] rows of this segment
+    double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
+    double* gbins;               // null: LDS bins; else the global Ψ vector flows are added to
     int nt_stores;               // use non-temporal stores for Delta/Lambda
 };
 

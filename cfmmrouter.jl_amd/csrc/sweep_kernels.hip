@@ -312,24 +312,32 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 
 // One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
 // partial row goes to partials[row].
-template <class Ops, bool MAT, int U, int BLOCK>
+// GBINS = true is the large-market mode (n_tokens > kMaxLdsTokens): v is gathered straight from
+// global memory (it stays L2-resident) and flows are added to ONE global Ψ vector with
+// global_atomic_add_f64 -- with that many tokens the same-address contention that rules
+// global atomics out for small n is gone.  The partial rows then carry only the dual scalar.
+template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     constexpr int kBlock = BLOCK;
     constexpr int kWaves = BLOCK / 64;
     extern __shared__ double lds[];
-    double* v_s = lds;                         // [n_pad]
-    double* bins = lds + a.n_pad;              // [copies][n_pad]
-    double* wsum = bins + (size_t)a.copies * a.n_pad; // [kWaves]
+    double* v_lds = lds;                                                      // [n_pad]
+    double* bins = lds + (GBINS ? 0 : a.n_pad);                               // [copies][n_pad]
+    double* wsum = GBINS ? lds : bins + (size_t)a.copies * a.n_pad;           // [kWaves]
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
+    const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
+    const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
 
     double* my_bins = bins + (size_t)(a.copies == 1 ? 0 : wave) * a.n_pad;
     double acc = 0.0;
 
     auto process = [&](const typename Ops::Raw& raw, int64_t i) {
         const int2 tok = ops.tokens(raw);
-        const double v1 = v_s[tok.x], v2 = v_s[tok.y];   // v[r.cfmms[i].Ai]
+        double v1, v2;                                   // v[r.cfmms[i].Ai]
+        if constexpr (GBINS) { v1 = a.v[tok.x]; v2 = a.v[tok.y]; }
+        else { v1 = v_lds[tok.x]; v2 = v_lds[tok.y]; }
         Trade t;
         ops.solve(raw, v1, v2, t);
         if (MAT) {
@@ -340,8 +348,13 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
         // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
         const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
-        if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
-        if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+        if constexpr (GBINS) {
+            if (f1 != 0.0) atomicAdd(&a.gbins[tok.x], f1);   // global_atomic_add_f64
+            if (f2 != 0.0) atomicAdd(&a.gbins[tok.y], f2);
+        } else {
+            if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
+            if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+        }
     };
 
     if constexpr (U == 1) {
@@ -355,8 +368,8 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         typename Ops::Raw cur;
         bool ok = i < a.m;
         if (ok) cur = ops.load(i);
-        for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
-        for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
+        for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
+        for (int j = tid; j < n_zero; j += kBlock) bins[j] = 0.0;
         __syncthreads();
         while (ok) {
             process(cur, i);
@@ -365,8 +378,8 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
             if (ok) cur = ops.load(i);
         }
     } else {
-        for (int j = tid; j < a.n; j += kBlock) v_s[j] = a.v[j];
-        for (int j = tid; j < a.copies * a.n_pad; j += kBlock) bins[j] = 0.0;
+        for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
+        for (int j = tid; j < n_zero; j += kBlock) bins[j] = 0.0;
         __syncthreads();
         const int64_t tile_pools = (int64_t)kBlock * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
@@ -392,8 +405,9 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     if ((tid & 63) == 0) wsum[wave] = acc;
     __syncthreads();
 
-    double* row = a.partials + (size_t)row_id * (a.n + 1);
-    for (int j = tid; j < a.n; j += kBlock) {
+    const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
+    double* row = a.partials + (size_t)row_id * (n_cols + 1);
+    for (int j = tid; j < n_cols; j += kBlock) {
         double s = bins[j];
         for (int c = 1; c < a.copies; ++c) s += bins[(size_t)c * a.n_pad + j];
         row[j] = s;
@@ -401,20 +415,20 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     if (tid == 0) {
         double s = wsum[0];
         for (int w = 1; w < kWaves; ++w) s += wsum[w];
-        row[a.n] = s;
+        row[n_cols] = s;
     }
 }
 
-template <class Ops, bool MAT, int U, int BLOCK>
+template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    sweep_body<Ops, MAT, U, BLOCK>(ops, a, blockIdx.x, gridDim.x, blockIdx.x);
+    sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, blockIdx.x, gridDim.x, blockIdx.x);
 }
 
 // Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
 // HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean / UniV3 blocks are co-resident on
 // every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
-template <bool MAT, int BLOCK>
+template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
     const int sidx = blockIdx.x % ma.nseg;
@@ -427,17 +441,17 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.Lambda = sg.Lambda;
     switch (sg.kind) {
     case 0:
-        sweep_body<ProductOps, MAT, 1, BLOCK>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
+        sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
         break;
     case 1:
         if (sg.pools.g.reference_order) {
-            sweep_body<GeoMeanOps, MAT, 1, BLOCK>(GeoMeanOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
+            sweep_body<GeoMeanOps, MAT, 1, BLOCK, GBINS>(GeoMeanOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         } else {
-            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
+            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         }
         break;
     default:
-        sweep_body<UniV3Ops, MAT, 1, BLOCK>(UniV3Ops{sg.pools.u}, a, local, nblocks, blockIdx.x);
+        sweep_body<UniV3Ops, MAT, 1, BLOCK, GBINS>(UniV3Ops{sg.pools.u}, a, local, nblocks, blockIdx.x);
         break;
     }
 }
@@ -511,6 +525,16 @@ static hipError_t set_lds_attr(size_t bytes)
 hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool mat, hipStream_t s)
 {
     dim3 g(grid);
+    if (ma.common.gbins) {
+        if (block == kBigBlock) {
+            if (mat) hipLaunchKernelGGL((sweep_multi<true, kBigBlock, true>), g, dim3(kBigBlock), lds_bytes, s, ma);
+            else hipLaunchKernelGGL((sweep_multi<false, kBigBlock, true>), g, dim3(kBigBlock), lds_bytes, s, ma);
+        } else {
+            if (mat) hipLaunchKernelGGL((sweep_multi<true, kSmallBlock, true>), g, dim3(kSmallBlock), lds_bytes, s, ma);
+            else hipLaunchKernelGGL((sweep_multi<false, kSmallBlock, true>), g, dim3(kSmallBlock), lds_bytes, s, ma);
+        }
+        return hipGetLastError();
+    }
     if (block == kBigBlock) {
         if (mat) hipLaunchKernelGGL((sweep_multi<true, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
         else hipLaunchKernelGGL((sweep_multi<false, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
@@ -543,6 +567,11 @@ template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid), b(B);
+    if (a.gbins) { // large-market mode, one pool per lane per tile only
+        if (mat) hipLaunchKernelGGL((sweep_kernel<Ops, true, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
+        else hipLaunchKernelGGL((sweep_kernel<Ops, false, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
+        return;
+    }
 #define CFMM_GO(MAT, U) hipLaunchKernelGGL((sweep_kernel<Ops, MAT, U, B>), g, b, c.lds_bytes, s, ops, a)
     if (mat) {
         if (c.unroll == 4) CFMM_GO(true, 4);

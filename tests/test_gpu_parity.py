@@ -236,8 +236,36 @@ def test_max_tokens():
     Do, Lo, psio, acco = oracle_sweep([b], n, v)
     np.testing.assert_array_equal(D, Do)
     assert rel_to_max(psi, psio) <= REDUCE_TOL
-    with pytest.raises(NotImplementedError):
-        cr.Context(8193)
+
+
+@pytest.mark.parametrize("n", [8193, 50_000])
+def test_large_market_global_bins(n):
+    """n_tokens > 8192: v gathered from global memory, flows added with global f64 atomics."""
+    segs = [synth.product_pools(120_000, n, seed=1), synth.geomean_pools(30_000, n, seed=2),
+            synth.univ3_pools(10_000, n, 3, seed=3)]
+    v = synth.sweep_prices(n, seed=5, spread=0.6)
+    for fuse in (1, 0):
+        D, L, psi, acc = device_sweep(segs, n, v, fuse_segments=fuse)
+        Do, Lo, psio, acco = oracle_sweep(segs, n, v)
+        np.testing.assert_array_equal(D[:120_000], Do[:120_000])
+        np.testing.assert_array_equal(D[150_000:], Do[150_000:])
+        assert np.max(np.abs(D - Do)) <= 1e-9 and np.max(np.abs(L - Lo)) <= 1e-9
+        assert rel_to_max(psi, psio) <= 1e-12
+        assert abs(acc - acco) <= 1e-11 * max(abs(acco), 1.0)
+    psi2 = device_sweep(segs, n, v, materialize=False)[2]
+    assert rel_to_max(psi2, psio) <= 1e-12
+
+
+def test_contexts_with_different_token_counts_coexist():
+    """the dynamic-LDS attribute is process-wide: a small context must not shrink a big one's limit"""
+    big = cr.DeviceBackend(8192, [synth.product_pools(5000, 8192, seed=1)])
+    small = cr.DeviceBackend(4, [synth.product_pools(50, 4, seed=2)])
+    huge = cr.DeviceBackend(20_000, [synth.product_pools(500, 20_000, seed=3)])
+    for be, n in ((small, 4), (huge, 20_000), (big, 8192), (small, 4)):
+        psi, _ = be.find_arb(synth.sweep_prices(n, seed=n))
+        assert np.all(np.isfinite(psi))
+    for be in (big, small, huge):
+        be.close()
 
 
 # ---- route! ---------------------------------------------------------------------------------------------
