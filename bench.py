@@ -219,7 +219,14 @@ def main():
     be.ctx.reset_stream()
     host = {}
     if world == 1:
-        for name, fn in (("eval", lambda: be.eval(v)), ("find_arb", lambda: be.find_arb(v))):
+        def eval_copy():
+            be.ctx.set_option("zero_copy", 0)
+            r = be.eval(v)
+            be.ctx.set_option("zero_copy", 1)
+            return r
+
+        for name, fn in (("eval", lambda: be.eval(v)), ("find_arb", lambda: be.find_arb(v)),
+                         ("eval_with_copy_commands", eval_copy)):
             for _ in range(5):
                 fn()
             t0 = time.perf_counter()

@@ -82,7 +82,8 @@ struct cfmm_ctx {
     double2* d_delta = nullptr;   // [trade_cap]
     double2* d_lambda = nullptr;
     int64_t trade_cap = 0;
-    double* h_stage = nullptr;    // pinned: [n] v in, [n+1] out
+    double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out
+    double* d_stage = nullptr;    // device address of h_stage
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
     bool have_out = false;
     bool have_trades = false;
@@ -97,6 +98,7 @@ struct cfmm_ctx {
     int64_t opt_nt_stores = 0;
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
+    int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -390,11 +392,19 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
             return fail(c, CFMM_ERR_INVALID_ARG, "v[%d] must be finite and > 0 (src/cfmms.jl:129)", j);
     HIP_TRY(c, hipSetDevice(c->device));
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int rc = enqueue_sweep(c, c->d_v, c->d_out, materialize);
-    if (rc != CFMM_OK) return rc;
     double* h_out = c->h_stage + c->n;
-    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (c->opt_zero_copy != 0 && !global_bins(c) && c->d_stage) {
+        // The kernels read v from, and the row fold writes {Ψ, acc} to, the pinned host staging
+        // buffer directly (it is mapped into the device's address space): no copy commands on
+        // the stream, one PCIe round trip for v hidden behind the first tile's pool loads.
+        int rc = enqueue_sweep(c, c->d_stage, c->d_stage + c->n, materialize);
+        if (rc != CFMM_OK) return rc;
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int rc = enqueue_sweep(c, c->d_v, c->d_out, materialize);
+        if (rc != CFMM_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->last_out.assign(h_out, h_out + c->n + 1);
     c->have_out = true;
@@ -460,7 +470,12 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     c->stream = c->own_stream;
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
-    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double),
+                            hipHostMallocMapped));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_stage), c->h_stage, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_stage = nullptr; // fall back to explicit copies
+    }
     // the dynamic-LDS ceiling is a per-function, process-wide attribute: always raise it to the
     // full 160 KiB so that contexts with different n_tokens cannot shrink each other's limit
     HIP_TRY_C(prepare_kernels(160 * 1024));
@@ -508,6 +523,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "nt_stores")) return &c->opt_nt_stores;
     if (!std::strcmp(key, "geomean_exact")) return &c->opt_geomean_exact;
     if (!std::strcmp(key, "fuse_segments")) return &c->opt_fuse_segments;
+    if (!std::strcmp(key, "zero_copy")) return &c->opt_zero_copy;
     return nullptr;
 }
 

@@ -205,6 +205,23 @@ def test_fused_equals_materialised_and_deterministic():
     be.close()
 
 
+def test_zero_copy_and_copy_paths_agree():
+    n = 100
+    b = synth.product_pools(40_000, n, seed=4)
+    be = cr.DeviceBackend(n, [b])
+    for seed in (1, 2, 3):          # fresh v every call: the kernels must see the new host values
+        v = synth.sweep_prices(n, seed=seed)
+        psi_z, acc_z = be.eval(v)
+        be.ctx.set_option("zero_copy", 0)
+        psi_c, acc_c = be.eval(v)
+        be.ctx.set_option("zero_copy", 1)
+        np.testing.assert_array_equal(psi_z, psi_c)
+        assert acc_z == acc_c
+        _, _, psio, _ = oracle_sweep([b], n, v)
+        assert rel_to_max(psi_z, psio) <= REDUCE_TOL
+    be.close()
+
+
 def test_empty_router_and_bad_inputs():
     be = cr.DeviceBackend(4, [])
     psi, acc = be.find_arb(np.ones(4))
