@@ -225,8 +225,8 @@ def main():
             be.ctx.set_option("zero_copy", 1)
             return r
 
-        for name, fn in (("eval", lambda: be.eval(v)), ("find_arb", lambda: be.find_arb(v)),
-                         ("eval_with_copy_commands", eval_copy)):
+        for name, fn in (("eval", lambda: be.eval(v)), ("eval_with_copy_commands", eval_copy),
+                         ("find_arb", lambda: be.find_arb(v))):
             for _ in range(5):
                 fn()
             t0 = time.perf_counter()
