@@ -225,7 +225,14 @@ def main():
             be.ctx.set_option("zero_copy", 1)
             return r
 
+        def eval_block():
+            be.ctx.set_option("spin_wait", 0)
+            r = be.eval(v)
+            be.ctx.set_option("spin_wait", 1)
+            return r
+
         for name, fn in (("eval", lambda: be.eval(v)), ("eval_with_copy_commands", eval_copy),
+                         ("eval_blocking_sync", eval_block),
                          ("find_arb", lambda: be.find_arb(v))):
             for _ in range(5):
                 fn()

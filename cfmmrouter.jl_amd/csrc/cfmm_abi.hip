@@ -99,6 +99,7 @@ struct cfmm_ctx {
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
+    int64_t opt_spin_wait = 1;     // 1: host-pointer calls busy-poll the stream instead of blocking
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -405,7 +406,15 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
         if (rc != CFMM_OK) return rc;
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->opt_spin_wait != 0) {
+        // busy-poll the stream instead of a blocking wait: the evaluation is ~30 us long and the
+        // caller (an L-BFGS-B step) has nothing else to do meanwhile
+        hipError_t q;
+        while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(c, CFMM_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     c->last_out.assign(h_out, h_out + c->n + 1);
     c->have_out = true;
     return CFMM_OK;
@@ -524,6 +533,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "geomean_exact")) return &c->opt_geomean_exact;
     if (!std::strcmp(key, "fuse_segments")) return &c->opt_fuse_segments;
     if (!std::strcmp(key, "zero_copy")) return &c->opt_zero_copy;
+    if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     return nullptr;
 }
 
