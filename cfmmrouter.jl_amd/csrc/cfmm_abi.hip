@@ -99,7 +99,7 @@ struct cfmm_ctx {
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
-    int64_t opt_spin_wait = 1;     // 1: host-pointer calls busy-poll the stream instead of blocking
+    int64_t opt_spin_wait = 0;     // 1: host-pointer calls busy-poll the stream (measured: no gain over hipStreamSynchronize)
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -191,9 +191,9 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
         s.block = kSmallBlock;
         s.grid = (int)std::min<int64_t>(tiles_small, c->opt_max_grid > 0 ? c->opt_max_grid : 2048);
     } else {
-        s.block = kBigBlock;
-        const int64_t tiles = std::max<int64_t>(1, (s.m + (int64_t)kBigBlock * U - 1) / ((int64_t)kBigBlock * U));
-        s.grid = (int)std::min<int64_t>(tiles, c->opt_max_grid > 0 ? c->opt_max_grid : 512);
+        s.block = c->opt_block == kMidBlock ? kMidBlock : kBigBlock;
+        const int64_t tiles = std::max<int64_t>(1, (s.m + (int64_t)s.block * U - 1) / ((int64_t)s.block * U));
+        s.grid = (int)std::min<int64_t>(tiles, c->opt_max_grid > 0 ? c->opt_max_grid : kResidentThreads / s.block);
     }
 }
 
@@ -208,25 +208,27 @@ int bin_copies(const cfmm_ctx* c, int block)
     const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block);
     if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
     // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
-    return per_wave <= (block == kBigBlock ? 80 : 64) * 1024 ? waves : 1;
+    return per_wave <= (block == kBigBlock ? 80 : (block == kMidBlock ? 48 : 32)) * 1024 ? waves : 1;
 }
 
 int ensure_geometry(cfmm_ctx* c)
 {
     if (!c->geometry_dirty) return CFMM_OK;
     int64_t rows = 0, trades = 0;
-    bool fusable = c->opt_fuse_segments != 0 && c->segs.size() >= 2;
+    bool fusable = c->opt_fuse_segments != 0 && c->segs.size() >= 2 && c->opt_geomean_exact == 0;
     bool any_big = false;
     for (auto& s : c->segs) {
         plan_segment(c, s);
         s.trade_off = trades;
         trades += s.m;
         fusable = fusable && s.unroll == 1;
-        any_big = any_big || s.block == kBigBlock;
+        any_big = any_big || s.block != kSmallBlock;
     }
     c->groups.clear();
     if (fusable) {
-        const int block = any_big ? kBigBlock : kSmallBlock;
+        // fused launches use 512-thread blocks: at ~75 VGPRs three of them fit a CU (24 wavefronts vs 16
+        // for one 1024-thread block) and Product / GeoMean blocks interleave on every CU
+        const int block = !any_big ? kSmallBlock : (c->opt_block == kBigBlock ? kBigBlock : kMidBlock);
         for (size_t first = 0; first < c->segs.size(); first += kMaxMulti) {
             Group g;
             g.first = (int)first;
@@ -240,7 +242,7 @@ int ensure_geometry(cfmm_ctx* c)
                 tiles = std::max<int64_t>(tiles, (sg.m + block - 1) / block);
             }
             const int64_t cap = std::max<int64_t>(
-                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kBigBlock ? 512 : 2048)) / g.nseg);
+                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kSmallBlock ? 2048 : kResidentThreads / block)) / g.nseg);
             const int per_seg = (int)std::min<int64_t>(tiles, cap);
             for (int k = 0; k < g.nseg; ++k) c->segs[first + k].grid = per_seg;
             g.grid = per_seg * g.nseg;
@@ -545,12 +547,13 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
     if (slot == &c->opt_max_grid && value < 0) return fail(c, CFMM_ERR_INVALID_ARG, "max_grid must be >= 0 (0 = auto)");
     if (slot == &c->opt_unroll && !(value == 0 || value == 1 || value == 2 || value == 4))
         return fail(c, CFMM_ERR_INVALID_ARG, "unroll must be 0 (auto), 1, 2 or 4");
-    if (slot == &c->opt_block && !(value == 0 || value == kSmallBlock || value == kBigBlock))
-        return fail(c, CFMM_ERR_INVALID_ARG, "block must be 0 (auto), %d or %d", kSmallBlock, kBigBlock);
+    if (slot == &c->opt_block && !(value == 0 || value == kSmallBlock || value == kMidBlock || value == kBigBlock))
+        return fail(c, CFMM_ERR_INVALID_ARG, "block must be 0 (auto), %d, %d or %d", kSmallBlock, kMidBlock, kBigBlock);
     if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == 2))
         return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 (shared) or 2 (per wavefront)");
     *slot = value;
-    if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments)
+    if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
+        slot == &c->opt_geomean_exact)
         c->geometry_dirty = true;
     return CFMM_OK;
 }

@@ -8,7 +8,9 @@
 namespace cfmm {
 
 constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
-constexpr int kBigBlock = 1024;      // 16 wavefronts: one or two fat blocks per CU, few partial rows
+constexpr int kMidBlock = 512;       // 8 wavefronts: fused multi-family launches (finer P/G interleave per CU)
+constexpr int kBigBlock = 1024;      // 16 wavefronts: single-family launches, few partial rows
+constexpr int kResidentThreads = 2048 * 256; // grid cap for the fat blocks: one machine of resident threads
 constexpr int kReduceBlock = 1024;
 constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
 constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 KiB LDS of a CU;
@@ -76,7 +78,7 @@ struct MultiArgs {
 };
 
 struct LaunchCfg {
-    int block;                   // kSmallBlock or kBigBlock
+    int block;                   // kSmallBlock, kMidBlock or kBigBlock
     int grid;
     int unroll;                  // 1, 2 or 4 pools per lane per tile
     size_t lds_bytes;

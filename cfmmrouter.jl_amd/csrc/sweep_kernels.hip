@@ -167,12 +167,11 @@ struct GeoMeanLogOps {
         double2 R, ew, lR;
         double g;
         int2 ai;
-        int64_t i;
     };
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        return Raw{p.R[i], p.ew[i], p.lR[i], p.gamma[i], p.Ai[i], i};
+        return Raw{p.R[i], p.ew[i], p.lR[i], p.gamma[i], p.Ai[i]};
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
@@ -183,22 +182,23 @@ struct GeoMeanLogOps {
         const double n2 = (g * v1) * R1, d2 = v2 * eta;     // c₂ = n2/d2: direction 2 trades iff c₂ > R₂
         const bool p1 = n1 > R1 * d1, p2 = n2 > R2 * d2;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        if (p1 != p2) {
-            const double lc = log((p1 ? n1 : n2) / (p1 ? d1 : d2));
-            const double ra = p1 ? R2 : R1, rb = p1 ? R1 : R2;
-            const double la = p1 ? r.lR.y : r.lR.x, lb = p1 ? r.lR.x : r.lR.y;
+        // pass 0: the (normally only) live direction.  pass 1: direction 2 when BOTH are live, which
+        // needs γ > 1 -- kept as a second trip through the same code (not a second copy of it) so the
+        // kernel's register footprint is that of one direction.
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool dir1 = pass == 0 && p1;
+            if (pass == 0 ? !(p1 || p2) : !(p1 && p2)) break;
+            const double lc = log((dir1 ? n1 : n2) / (dir1 ? d1 : d2));
+            const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
+            const double la = dir1 ? r.lR.y : r.lR.x, lb = dir1 ? r.lR.x : r.lR.y;
             const double u = (lb - lc) + la;
-            const double A = p1 ? (lc + eta * lb) : (eta * lc + lb);
-            const double B = p1 ? (la + eta * u) : (eta * la + u);
+            const double A = dir1 ? (lc + eta * lb) : (eta * lc + lb);
+            const double B = dir1 ? (la + eta * u) : (eta * la + u);
             const double d = max0(exp(A * inv) - rb) / g;
             const double l = max0(ra - exp(B * inv));
-            t.d1 = p1 ? d : 0.0;
-            t.d2 = p1 ? 0.0 : d;
-            t.l1 = p1 ? 0.0 : l;
-            t.l2 = p1 ? l : 0.0;
-        } else if (p1) {   // γ > 1: both directions "trade"; keep the reference's arithmetic
-            GeoMeanOps ref{p};
-            ref.solve(GeoMeanOps::Raw{r.R, p.w[r.i], r.g, r.ai}, v1, v2, t);
+            if (dir1) { t.d1 = d; t.l2 = l; }
+            else { t.d2 = d; t.l1 = l; }
         }
     }
 };
@@ -443,12 +443,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     case 0:
         sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
         break;
-    case 1:
-        if (sg.pools.g.reference_order) {
-            sweep_body<GeoMeanOps, MAT, 1, BLOCK, GBINS>(GeoMeanOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
-        } else {
-            sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
-        }
+    case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
+        sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         break;
     default:
         sweep_body<UniV3Ops, MAT, 1, BLOCK, GBINS>(UniV3Ops{sg.pools.u}, a, local, nblocks, blockIdx.x);
@@ -516,32 +512,30 @@ static hipError_t set_lds_attr(size_t bytes)
 #define CFMM_SET_B(B)                                                                                 \
     CFMM_SET(true, 1, B) CFMM_SET(true, 2, B) CFMM_SET(true, 4, B)                                    \
     CFMM_SET(false, 1, B) CFMM_SET(false, 2, B) CFMM_SET(false, 4, B)
-    CFMM_SET_B(256) CFMM_SET_B(1024)
+    CFMM_SET_B(kSmallBlock) CFMM_SET_B(kMidBlock) CFMM_SET_B(kBigBlock)
 #undef CFMM_SET_B
 #undef CFMM_SET
     return hipSuccess;
 }
 
+template <int B>
+static void launch_multi_b(const MultiArgs& ma, int grid, size_t lds_bytes, bool mat, hipStream_t s)
+{
+    dim3 g(grid), b(B);
+    if (ma.common.gbins) {
+        if (mat) hipLaunchKernelGGL((sweep_multi<true, B, true>), g, b, lds_bytes, s, ma);
+        else hipLaunchKernelGGL((sweep_multi<false, B, true>), g, b, lds_bytes, s, ma);
+    } else {
+        if (mat) hipLaunchKernelGGL((sweep_multi<true, B, false>), g, b, lds_bytes, s, ma);
+        else hipLaunchKernelGGL((sweep_multi<false, B, false>), g, b, lds_bytes, s, ma);
+    }
+}
+
 hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool mat, hipStream_t s)
 {
-    dim3 g(grid);
-    if (ma.common.gbins) {
-        if (block == kBigBlock) {
-            if (mat) hipLaunchKernelGGL((sweep_multi<true, kBigBlock, true>), g, dim3(kBigBlock), lds_bytes, s, ma);
-            else hipLaunchKernelGGL((sweep_multi<false, kBigBlock, true>), g, dim3(kBigBlock), lds_bytes, s, ma);
-        } else {
-            if (mat) hipLaunchKernelGGL((sweep_multi<true, kSmallBlock, true>), g, dim3(kSmallBlock), lds_bytes, s, ma);
-            else hipLaunchKernelGGL((sweep_multi<false, kSmallBlock, true>), g, dim3(kSmallBlock), lds_bytes, s, ma);
-        }
-        return hipGetLastError();
-    }
-    if (block == kBigBlock) {
-        if (mat) hipLaunchKernelGGL((sweep_multi<true, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
-        else hipLaunchKernelGGL((sweep_multi<false, kBigBlock>), g, dim3(kBigBlock), lds_bytes, s, ma);
-    } else {
-        if (mat) hipLaunchKernelGGL((sweep_multi<true, kSmallBlock>), g, dim3(kSmallBlock), lds_bytes, s, ma);
-        else hipLaunchKernelGGL((sweep_multi<false, kSmallBlock>), g, dim3(kSmallBlock), lds_bytes, s, ma);
-    }
+    if (block == kBigBlock) launch_multi_b<kBigBlock>(ma, grid, lds_bytes, mat, s);
+    else if (block == kMidBlock) launch_multi_b<kMidBlock>(ma, grid, lds_bytes, mat, s);
+    else launch_multi_b<kSmallBlock>(ma, grid, lds_bytes, mat, s);
     return hipGetLastError();
 }
 
@@ -552,7 +546,8 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     em = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_multi<MAT, B>),                     \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);         \
     if (em != hipSuccess) return em;
-    CFMM_SETM(true, kBigBlock) CFMM_SETM(false, kBigBlock) CFMM_SETM(true, kSmallBlock) CFMM_SETM(false, kSmallBlock)
+    CFMM_SETM(true, kBigBlock) CFMM_SETM(false, kBigBlock) CFMM_SETM(true, kMidBlock) CFMM_SETM(false, kMidBlock)
+    CFMM_SETM(true, kSmallBlock) CFMM_SETM(false, kSmallBlock)
 #undef CFMM_SETM
     hipError_t e = set_lds_attr<ProductOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
@@ -589,8 +584,9 @@ template <class Ops>
 static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     if (a.m <= 0) return hipSuccess;
-    if (c.block == 1024) launch_block<Ops, 1024>(ops, a, c, mat, s);
-    else launch_block<Ops, 256>(ops, a, c, mat, s);
+    if (c.block == kBigBlock) launch_block<Ops, kBigBlock>(ops, a, c, mat, s);
+    else if (c.block == kMidBlock) launch_block<Ops, kMidBlock>(ops, a, c, mat, s);
+    else launch_block<Ops, kSmallBlock>(ops, a, c, mat, s);
     return hipGetLastError();
 }
 

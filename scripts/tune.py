@@ -42,8 +42,8 @@ def run(mat, steps=30, **opts):
 
 print(f"# {what} m={m} n={n}  (event-timed: ~2.5 us above rocprof's kernel duration)")
 print("block unroll max_grid copies nt | sweep_us(mat) sweep_us(fused) reduce_us grid")
-for block, unroll, mg, cp, nt in itertools.product([256, 1024], [1, 2, 4], [256, 512, 1024, 2048], [1, 2], [0, 1]):
-    if block == 1024 and mg > 512:
+for block, unroll, mg, cp, nt in itertools.product([256, 512, 1024], [1, 2, 4], [256, 512, 1024, 2048], [1, 2], [0, 1]):
+    if block >= 512 and mg > 1024:
         continue
     if block == 256 and mg < 1024:
         continue

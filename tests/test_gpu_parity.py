@@ -89,7 +89,7 @@ def test_product_sweep_bit_exact(m, n):
 
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("copies", [1, 2])
-@pytest.mark.parametrize("block", [256, 1024])
+@pytest.mark.parametrize("block", [256, 512, 1024])
 def test_product_launch_variants(unroll, copies, block):
     m, n = 70_001, 96
     b = synth.product_pools(m, n, seed=3)
