@@ -335,6 +335,30 @@ def test_route_basket_liquidation_parity():
     r.close()
 
 
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+@pytest.mark.parametrize("shape", ["config3", "config5"])
+def test_route_named_config_shapes(shape, solver):
+    """BASELINE configs 3 and 5 in miniature (the reference has no router-level test with
+    GeometricMeanTwoCoin or UniV3 pools): route! parity against the CPU restatement."""
+    n = 64
+    if shape == "config3":   # mixed ProductTwoCoin + GeometricMeanTwoCoin, LinearNonnegative arbitrage
+        market = [synth.product_pools(20_000, n, seed=31), synth.geomean_pools(20_000, n, seed=32)]
+        obj, v0 = cr.LinearNonnegative(synth.linear_prices(n, seed=31)), np.ones(n)
+    else:                    # BoundedProduct (2-tick UniV3) pools, BasketLiquidation
+        market = [synth.bounded_product_pools(40_000, n, seed=33)]
+        obj, v0 = cr.BasketLiquidation(1, synth.basket(n, seed=33)), None
+    r = cr.Router(obj, market, n)
+    cr.route_(r, v=v0, solver=solver)
+    ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(r._batches, n), v0=v0, nthreads=8)
+    assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
+    assert abs(r.info["f"] - ref["f"]) <= 1e-9 * max(1.0, abs(ref["f"]))
+    if shape == "config5":
+        Ψ = cr.netflows(r)
+        assert Ψ[0] > 0                                   # something was received in the output token
+        assert np.all(Ψ[1:] + obj.Δin[1:] >= -1e-3 - 1e-8 * np.max(np.abs(Ψ)))   # basket constraint Ψ₋ᵢ + Δin₋ᵢ ≥ 0
+    r.close()
+
+
 @pytest.mark.parametrize("kind", ["arb", "basket", "mixed"])
 def test_route_native_solver_one_call(kind):
     """cfmm_route: the whole of route! inside the library (own L-BFGS-B) vs the CPU restatement."""
