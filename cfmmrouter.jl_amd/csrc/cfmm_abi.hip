@@ -397,10 +397,16 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
     double* h_out = c->h_stage + c->n;
     if (c->opt_zero_copy != 0 && !global_bins(c) && c->d_stage) {
-        // The kernels read v from, and the row fold writes {Ψ, acc} to, the pinned host staging
-        // buffer directly (it is mapped into the device's address space): no copy commands on
-        // the stream, one PCIe round trip for v hidden behind the first tile's pool loads.
-        int rc = enqueue_sweep(c, c->d_stage, c->d_stage + c->n, materialize);
+        // The row fold writes {Ψ, acc} straight into the pinned host staging buffer (mapped into
+        // the device's address space), and for small n every block also reads v from it: no copy
+        // commands on the stream, the PCIe round trip for v hides behind the first tile's pool
+        // loads.  Larger v (every block re-reads it) goes through one H2D copy instead.
+        const double* v_src = c->d_stage;
+        if (c->n > 1024) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            v_src = c->d_v;
+        }
+        int rc = enqueue_sweep(c, v_src, c->d_stage + c->n, materialize);
         if (rc != CFMM_OK) return rc;
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
