@@ -1,0 +1,40 @@
+"""Copies the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked), named per round."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+for d in glob.glob(os.path.join(src, "prof_*")):
+    if not os.path.isdir(d):
+        continue
+    w = os.path.basename(d)[5:]
+    for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "tune_*.txt")):
+    shutil.copy(f, os.path.join(dst, f"{rnd}_{os.path.basename(f)}"))
+if os.path.exists(os.path.join(src, "traffic.json")):
+    shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, "traffic.json"))
+for f in glob.glob(os.path.join(src, "benchfull_*.log")):
+    lines = [x for x in open(f) if x.startswith("{")]
+    if lines:
+        w = os.path.basename(f)[10:-4]
+        json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{rnd}_bench_{w}.json"), "w"), indent=1)
+for w in {os.path.basename(d).split("_")[1] for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)}:
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(src, f"pmc_{w}_{c}", "*counter_collection.csv"))
+        acc = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == c and "cfmm" in row["Kernel_Name"]:
+                    acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+        out[c] = {k: {"launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
+                  for k, v in acc.items()}
+    json.dump(out, open(os.path.join(dst, f"{rnd}_{w}_pmc_summary.json"), "w"), indent=1)
+print(sorted(os.listdir(dst)))
