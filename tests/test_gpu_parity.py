@@ -87,6 +87,60 @@ def test_product_sweep_bit_exact(m, n):
     assert abs(acc - acco) <= REDUCE_TOL * max(abs(acco), 1.0)
 
 
+def test_product_bit_exact_over_wide_dynamic_range():
+    """The direction-select evaluation must equal the reference's four closed forms bit for bit
+    everywhere, including pools sitting exactly on / next to the no-arbitrage boundary."""
+    rng = np.random.default_rng(2024)
+    m, n = 400_000, 32
+    R = 10.0 ** rng.uniform(-9, 12, (m, 2))
+    γ = rng.choice([1.0, 0.997, 0.9999999999, 0.5, 0.01, 1.0 - 2.0 ** -52], m)
+    Ai = synth.token_pairs(9, 1, m, n)
+    v = 10.0 ** rng.uniform(-6, 6, n)
+    # a quarter of the pools are placed ON the boundary v1·R1 == γ·v2·R2 (up to rounding), and
+    # another quarter at the no-fee parity point v1·R1 == v2·R2
+    i1, i2 = Ai[:, 0] - 1, Ai[:, 1] - 1
+    q = m // 4
+    R[:q, 0] = γ[:q] * v[i2[:q]] * R[:q, 1] / v[i1[:q]]
+    R[q:2 * q, 0] = v[i2[q:2 * q]] * R[q:2 * q, 1] / v[i1[q:2 * q]]
+    R[:2 * q, 0] *= 1.0 + rng.integers(-3, 4, 2 * q) * 2.0 ** -52      # ± a few ulp around it
+    b = cr.ProductTwoCoin.batch(R, γ, Ai)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert np.count_nonzero(D[:2 * q]) > 0 and np.count_nonzero(D[:2 * q] == 0) > 0
+    assert rel_to_max(psi, psio) <= 1e-11
+
+
+def test_univ3_bit_exact_ragged_and_degenerate():
+    """ragged tick counts 1..40, empty current ticks, prices on tick boundaries, γ = 1 and tiny."""
+    rng = np.random.default_rng(7)
+    m, n = 30_000, 16
+    nt = rng.integers(1, 41, m)
+    off = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(nt, out=off[1:])
+    T = int(off[-1])
+    ticks, liq, cp = np.empty(T), np.empty(T), np.empty(m)
+    for i in range(m):
+        t = np.sort(10.0 ** rng.uniform(-3, 3, nt[i]))[::-1]
+        t *= 1.0 + np.arange(nt[i])[::-1] * 1e-9            # strictly descending even on ties
+        ticks[off[i]:off[i + 1]] = t
+        lq = 10.0 ** rng.uniform(-2, 6, nt[i])
+        lq[rng.random(nt[i]) < 0.3] = 0.0                   # empty ticks, possibly the current one
+        liq[off[i]:off[i + 1]] = lq
+        k = rng.integers(0, nt[i])
+        cp[i] = t[k] if rng.random() < 0.3 else t[k] * rng.uniform(0.5, 1.0)   # on a boundary 30 % of the time
+    γ = rng.choice([1.0, 0.997, 0.3], m)
+    b = cr.UniV3.batch(cp, off, ticks, liq, γ, synth.token_pairs(5, 1, m, n))
+    for spread in (0.05, 3.0):
+        v = synth.sweep_prices(n, seed=int(spread * 100), spread=spread)
+        D, L, psi, acc = device_sweep([b], n, v)
+        Do, Lo, psio, acco = oracle_sweep([b], n, v)
+        np.testing.assert_array_equal(D, Do)
+        np.testing.assert_array_equal(L, Lo)
+        assert rel_to_max(psi, psio) <= 1e-11
+
+
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("copies", [1, 2])
 @pytest.mark.parametrize("block", [256, 512, 1024])
