@@ -157,7 +157,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun even N=1 goes through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -178,14 +179,14 @@ def main():
 
     def step():
         be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
 
     for _ in range(args.warmup):
         step()
 
     def timed_pass():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -195,7 +196,7 @@ def main():
             step()
         ev1.record(stream)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
@@ -209,7 +210,7 @@ def main():
     elapsed2, _ = timed_pass()
     kt = be.ctx.kernel_times()
     be.ctx.set_option("time_kernels", 0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -268,7 +269,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
                    "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
-                   "sharding": f"pools x{world}, all-reduce of n_tokens+1 f64 per step" if world > 1 else "single GPU"},
+                   "sharding": (f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step" if use_dist
+                                else "single GPU, no collective")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "cfmm::sweep_kernel (all segment launches of one step)",
@@ -298,7 +300,7 @@ def main():
     be.close()
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
