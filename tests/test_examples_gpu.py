@@ -1,0 +1,53 @@
+"""The reference's three examples (examples/arbitrage.jl, liquidate.jl, Univ3.jl) run on the device
+through the host mirror and are checked against the CPU restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+import cfmmrouter_amd as cr
+from oracle import cfmm_oracle as orc
+from helpers import oracle_objective, oracle_poolset, rel_to_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+def test_arbitrage_example(solver, capsys):
+    import arbitrage
+    Ψ, v, D, L = arbitrage.main(solver)
+    assert "Profit" in capsys.readouterr().out
+    pools = [cr.ProductTwoCoin.batch([[1e6, 1e6], [1e3, 2e3]], [1, 1], [[1, 2], [1, 2]]),
+             cr.GeometricMeanTwoCoin.batch([[1e4, 2e4]], [[.4, .6]], [1], [[1, 2]])]
+    ref = orc.route_oracle(oracle_objective(cr.LinearNonnegative(np.ones(2))), oracle_poolset(pools, 2))
+    assert rel_to_max(Ψ, ref["psi"]) <= 1e-6
+    assert np.all(Ψ >= -1e-3) and Ψ.sum() > 100           # an arbitrage profit exists in this market
+    np.testing.assert_allclose(D, ref["Delta"], atol=1e-4 * np.max(ref["Delta"]))
+
+
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+def test_liquidate_example(solver, capsys):
+    import liquidate
+    (Ψ1, v1), (Ψ2, v2) = liquidate.main(solver)
+    assert "Amount received" in capsys.readouterr().out
+    pools = [cr.ProductTwoCoin.batch([[1e3, 1e4], [1e3, 1e2], [1e3, 2e4]], [0.997] * 3, [[1, 2], [2, 3], [1, 3]])]
+    for Ψ, (i, Din) in ((Ψ1, (1, [0, 1e1, 1e2])), (Ψ2, (2, [1e1, 0.0, 0.0]))):
+        ref = orc.route_oracle(oracle_objective(cr.BasketLiquidation(i, Din)), oracle_poolset(pools, 3))
+        assert rel_to_max(Ψ, ref["psi"]) <= 1e-6
+        assert Ψ[i - 1] > 0                                             # something is received
+        others = [j for j in range(3) if j != i - 1]
+        np.testing.assert_allclose(Ψ[others], -np.asarray(Din)[others], atol=1e-3)  # the basket is fully tendered
+
+
+def test_univ3_example(capsys):
+    import univ3
+    Δ, Λ = univ3.main()
+    out = capsys.readouterr().out
+    assert "Tendered basket" in out and "2: 1.373" in out and "1: 0.072" in out   # SURVEY §3.4 hand trace
+    D, L = orc.UniV3(15.0, [30.0, 20, 10, 5], [1.0, 2.0, 1.5, 0.0], 0.997).find_arb([25.0, 1.0])
+    np.testing.assert_array_equal(Δ, D)
+    np.testing.assert_array_equal(Λ, L)
