@@ -47,7 +47,7 @@ def test_univ3_example(capsys):
     import univ3
     Δ, Λ = univ3.main()
     out = capsys.readouterr().out
-    assert "Tendered basket" in out and "2: 1.373" in out and "1: 0.072" in out   # SURVEY §3.4 hand trace
+    assert "Tendered basket" in out and "2: 1.37" in out and "1: 0.072" in out   # SURVEY §3.4 hand trace (≈1.373, ≈0.0722)
     D, L = orc.UniV3(15.0, [30.0, 20, 10, 5], [1.0, 2.0, 1.5, 0.0], 0.997).find_arb([25.0, 1.0])
     np.testing.assert_array_equal(Δ, D)
     np.testing.assert_array_equal(Λ, L)
