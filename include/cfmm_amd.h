@@ -138,6 +138,21 @@ int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lamb
 int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
                       int64_t* reduce_launches, double* reduce_ms);
 
+/* ---- sharded runs: low-latency all-reduce of {psi, acc} over xGMI peer mappings ------------ */
+
+/* One-shot all-reduce(sum) of `count` doubles across the `world` GPUs of one node.  peer_buffers[p]
+ * is the device address, mapped into THIS process, of rank p's symmetric buffer laid out as
+ * [2][count] doubles followed by 2 uint64 flags, zero-initialised before first use (e.g. a
+ * torch.distributed._symmetric_memory allocation: hdl.buffer_ptrs).  Before the call, this rank's
+ * contribution must have been written (on the same stream) to its own buffer at
+ * [seq & 1][0..count) -- cfmm_sweep_dev can target it directly.  seq starts at 1 and increases by
+ * one per call on every rank.  Every rank sums the peers in rank order, so all ranks obtain
+ * bit-identical results.  Asynchronous on hip_stream; if a peer does not publish within about a
+ * second the output is filled with NaN instead of hanging.  Replaces nothing in the reference
+ * (it has no distributed path); it is the collective of SURVEY 8e. */
+int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t world, int32_t rank,
+                        int64_t count, uint64_t seq, double* d_out);
+
 /* ---- route! without an interpreter in the loop ----------------------- */
 
 #define CFMM_OBJ_LINEAR_NONNEGATIVE 0 /* LinearNonnegative(c)      src/objectives.jl:51-79 */
