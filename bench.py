@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and route legs")
     ap.add_argument("--fused", action="store_true", help="time the fused evaluation (no Δ/Λ write-back)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
+    ap.add_argument("--rccl", action="store_true", help="force the RCCL all-reduce instead of the one-shot peer gather")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,11 +177,19 @@ def main():
     v_t = torch.from_numpy(v).to("cuda")
     out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
     materialize = not args.fused
+    peer = None
+    if use_dist and not args.rccl:
+        from cfmmrouter_amd.dist import PeerAllReduce
+        peer = PeerAllReduce.create(n + 1, None, torch.device("cuda", local_rank))  # None -> RCCL fallback
 
     def step():
-        be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
-        if use_dist:
-            dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
+        if peer is not None:   # fold into the symmetric slot, then the one-shot xGMI gather (rank-ordered sum)
+            be.ctx.sweep_dev(v_t.data_ptr(), peer.slot().data_ptr(), materialize)
+            peer.reduce(out_t)
+        else:
+            be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+            if use_dist:
+                dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
 
     for _ in range(args.warmup):
         step()
@@ -269,8 +278,9 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
                    "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
-                   "sharding": (f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step" if use_dist
-                                else "single GPU, no collective")},
+                   "sharding": ((f"pools x{world}, one-shot xGMI peer all-reduce of n_tokens+1 f64 per step"
+                                 if peer is not None else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
+                                if use_dist else "single GPU, no collective")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "cfmm::sweep_kernel (all segment launches of one step)",

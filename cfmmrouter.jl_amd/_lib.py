@@ -113,6 +113,8 @@ def lib():
                              C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(RouteInfo)]
     L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
                                        C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
+    L.cfmm_peer_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64,
+                                      C.c_uint64, C.c_void_p]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
     L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p, _i32p]

@@ -21,6 +21,79 @@ from .cfmms import PoolBatch
 from .router import DeviceBackend, Router, _segments_of
 
 
+class PeerAllReduce:
+    """One-shot all-reduce(sum) of {Ψ, acc} over xGMI peer mappings (csrc/peer_allreduce.hip).
+
+    The buffers are a torch.distributed._symmetric_memory allocation (torch does the IPC handle
+    exchange); the kernel is ours.  `slot()` is where this step's local {Ψ, acc} must be written
+    (cfmm_sweep_dev targets it directly), `reduce(out)` then leaves the rank-ordered sum in `out` on
+    every rank.  `PeerAllReduce.create` returns None whenever anything about the fast path is not
+    available or does not reproduce RCCL's result on a self-test -- callers then use dist.all_reduce."""
+
+    def __init__(self, count, group, device):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+        import torch.distributed._symmetric_memory as symm_mem
+
+        from ._lib import lib
+
+        self._torch, self._C, self._lib = torch, C, lib()
+        self.count = int(count)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        words = 2 * self.count + 2                       # [2][count] doubles + 2 uint64 flags
+        self.buf = symm_mem.empty(words, dtype=torch.float64, device=device)
+        self.buf.zero_()
+        gname = (group or dist.group.WORLD).group_name
+        self.hdl = symm_mem.rendezvous(self.buf, gname)
+        ptrs = [int(p) for p in self.hdl.buffer_ptrs]
+        if len(ptrs) != self.world:
+            raise RuntimeError("symmetric memory returned an unexpected number of peers")
+        self._ptrs = (C.c_uint64 * self.world)(*ptrs)
+        self.seq = 0
+        torch.cuda.synchronize(device)
+        self.hdl.barrier()                               # everybody's flags are zero before step 1
+        torch.cuda.synchronize(device)
+
+    def slot(self):
+        """Device view [count] that the NEXT reduce() will read as this rank's contribution."""
+        parity = (self.seq + 1) & 1
+        return self.buf[parity * self.count:(parity + 1) * self.count]
+
+    def reduce(self, out):
+        self.seq += 1
+        stream = self._torch.cuda.current_stream().cuda_stream
+        rc = self._lib.cfmm_peer_allreduce(self._C.c_void_p(stream), self._ptrs, self.world, self.rank, self.count,
+                                           self._C.c_uint64(self.seq), self._C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise RuntimeError("cfmm_peer_allreduce launch failed")
+
+    @staticmethod
+    def create(count, group, device, checks=4):
+        import torch
+        import torch.distributed as dist
+        try:
+            par = PeerAllReduce(count, group, device)
+            good = True
+            out = torch.empty(count, dtype=torch.float64, device=device)
+            for k in range(checks):   # self-test against RCCL before trusting the fast path
+                g = torch.Generator(device="cpu").manual_seed(1000 * k + par.rank)
+                x = torch.rand(count, dtype=torch.float64, generator=g).to(device) * (10.0 ** k)
+                par.slot().copy_(x)
+                par.reduce(out)
+                ref = x.clone()
+                dist.all_reduce(ref, group=group)
+                torch.cuda.synchronize(device)
+                scale = float(ref.abs().max())
+                good = good and bool(torch.isfinite(out).all()) and float((out - ref).abs().max()) <= 1e-12 * scale
+        except Exception:
+            par, good = None, False
+        flag = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)   # all ranks or none
+        return par if float(flag.item()) == 1.0 else None
+
+
 def shard_range(m: int, rank: int, world: int):
     """Contiguous block [lo, hi) of m items owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(int(m), int(world))
@@ -57,6 +130,10 @@ class ShardedBackend:
             self._out_pin = torch.empty(self.n_tokens + 1, dtype=torch.float64).pin_memory()
             self._dev = dev
             self._stream = torch.cuda.Stream(device=dev)   # sweep, all-reduce and copies share it
+            self._peer = None
+            if dist.get_backend(group) == "nccl":
+                with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+                    self._peer = PeerAllReduce.create(self.n_tokens + 1, group, dev)
 
     def _reduce_host(self, psi, acc):
         t = self._torch.from_numpy(np.concatenate([psi, [acc]]))
@@ -74,8 +151,12 @@ class ShardedBackend:
             self.local.ctx.set_stream(stream.cuda_stream)
             self._v_pin.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)))
             self._v.copy_(self._v_pin, non_blocking=True)
-            self.local.ctx.sweep_dev(self._v.data_ptr(), self._out.data_ptr(), materialize)
-            self._dist.all_reduce(self._out, group=self.group)   # RCCL, 8·(n_tokens+1) bytes
+            if self._peer is not None:      # fold straight into the symmetric slot, one-shot gather over xGMI
+                self.local.ctx.sweep_dev(self._v.data_ptr(), self._peer.slot().data_ptr(), materialize)
+                self._peer.reduce(self._out)
+            else:
+                self.local.ctx.sweep_dev(self._v.data_ptr(), self._out.data_ptr(), materialize)
+                self._dist.all_reduce(self._out, group=self.group)   # RCCL, 8·(n_tokens+1) bytes
             self._out_pin.copy_(self._out, non_blocking=True)
             stream.synchronize()
         out = self._out_pin.numpy()
