@@ -62,6 +62,8 @@ WORKLOADS = {
                      lambda rank: [synth.product_pools(500_000, 512, seed=1234, first=rank * 500_000)]),
     "config5": ("1M BoundedProduct (2-tick UniV3) pools, 256 tokens, BasketLiquidation", 256,
                 lambda rank: [synth.bounded_product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
+    "large_n": ("1M ProductTwoCoin pools, 65536 tokens (global-bin path), LinearNonnegative arbitrage", 65536,
+                lambda rank: [synth.product_pools(1_000_000, 65536, seed=1234, first=rank * 1_000_000)]),
     "product1m": ("1M ProductTwoCoin pools, 256 tokens, LinearNonnegative arbitrage", 256,
                   lambda rank: [synth.product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
 }
