@@ -302,7 +302,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
 {
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
-    const bool timed = c->opt_time_kernels != 0;
+    const bool timed = c->opt_time_kernels != 0 && c->pending.size() < (1u << 20); // harvest with cfmm_kernel_times
     const bool gb = global_bins(c);
     HIP_TRY(c, hipSetDevice(c->device));
     if (gb) HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)c->n * sizeof(double), c->stream));
@@ -505,6 +505,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& s : c->segs) free_segment(s);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);

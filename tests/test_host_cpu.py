@@ -264,3 +264,17 @@ def test_market_file_round_trip(tmp_path):
             else:
                 np.testing.assert_array_equal(a.lower_ticks, b.lower_ticks)
                 np.testing.assert_array_equal(a.tick_off, b.tick_off)
+
+
+def test_c_abi_error_codes_without_device():
+    """Argument validation that does not need a GPU, straight through ctypes."""
+    import ctypes as C
+    L = cr.lib()
+    h = C.c_void_p()
+    assert L.cfmm_ctx_create(0, 0, C.byref(h)) == -1 and b"n_tokens" in L.cfmm_last_error(None)
+    assert L.cfmm_ctx_create(0, 4, None) == -1
+    assert L.cfmm_ctx_create(0, (1 << 26) + 1, C.byref(h)) == -4
+    assert L.cfmm_pools_count(None) == 0 and L.cfmm_n_tokens(None) == 0 and L.cfmm_segment_count(None) == 0
+    assert L.cfmm_set_stream(None, None) == -1 and L.cfmm_find_arb(None, None) == -1
+    assert L.cfmm_peer_allreduce(None, None, 1, 0, 4, 1, None) == -1
+    assert b"gfx950" in L.cfmm_version()
