@@ -51,6 +51,7 @@ struct Segment {
     int grid = 0;
     int unroll = 1;
     int64_t row_off = 0; // first partial row
+    std::vector<int32_t> h_ai; // host copy of Ai, kept only in large-market mode (incidence build)
 };
 
 // A launch: either one segment (sweep_kernel) or up to kMaxMulti segments fused (sweep_multi).
@@ -82,6 +83,13 @@ struct cfmm_ctx {
     double2* d_delta = nullptr;   // [trade_cap]
     double2* d_lambda = nullptr;
     int64_t trade_cap = 0;
+    // large-market mode (n > kMaxLdsTokens): token -> (pool, side) incidence and flow scratch
+    double2* d_flow = nullptr;    // [m_total] {Λ₁−Δ₁, Λ₂−Δ₂}
+    int* d_entries = nullptr;     // [2·m_total] flat flow indices grouped by token
+    int2* d_chunks = nullptr;     // [n_chunks] {begin, end} into d_entries
+    int* d_tok_chunk_off = nullptr; // [n+1]
+    double* d_chunk_sums = nullptr; // [n_chunks]
+    int n_chunks = 0;
     double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out
     double* d_stage = nullptr;    // device address of h_stage
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
@@ -211,6 +219,42 @@ int bin_copies(const cfmm_ctx* c, int block)
     return per_wave <= (block == kBigBlock ? 80 : (block == kMidBlock ? 48 : 32)) * 1024 ? waves : 1;
 }
 
+// Large-market mode: token -> (pool, side) incidence in CSR form, cut into chunks of at most
+// kGatherChunk entries (hub tokens are spread over many wavefronts), plus the flow scratch.
+int build_incidence(cfmm_ctx* c)
+{
+    const int64_t m = c->m_total;
+    if (2 * m > (int64_t)INT32_MAX) return fail(c, CFMM_ERR_UNSUPPORTED, "large-market mode supports up to 2^30 pools");
+    std::vector<int> off((size_t)c->n + 1, 0);
+    for (const auto& s : c->segs)
+        for (int64_t k = 0; k < 2 * s.m; ++k) ++off[(size_t)s.h_ai[(size_t)k] + 1];
+    for (int t = 0; t < c->n; ++t) off[(size_t)t + 1] += off[(size_t)t];
+    std::vector<int> entries((size_t)(2 * m)), cursor(off.begin(), off.end() - 1);
+    for (const auto& s : c->segs)
+        for (int64_t i = 0; i < s.m; ++i)
+            for (int side = 0; side < 2; ++side)
+                entries[(size_t)cursor[(size_t)s.h_ai[(size_t)(2 * i + side)]]++] = (int)(2 * (s.trade_off + i) + side);
+    std::vector<int2> chunks;
+    std::vector<int> tok_chunk_off((size_t)c->n + 1, 0);
+    for (int t = 0; t < c->n; ++t) {
+        for (int b = off[(size_t)t]; b < off[(size_t)t + 1]; b += kGatherChunk)
+            chunks.push_back(make_int2(b, std::min(b + kGatherChunk, off[(size_t)t + 1])));
+        tok_chunk_off[(size_t)t + 1] = (int)chunks.size();
+    }
+    (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
+    (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
+    c->d_flow = nullptr; c->d_entries = nullptr; c->d_chunks = nullptr; c->d_tok_chunk_off = nullptr; c->d_chunk_sums = nullptr;
+    c->n_chunks = (int)chunks.size();
+    int rc;
+    if ((rc = upload(c, &c->d_entries, entries.data(), entries.size())) ||
+        (rc = upload(c, &c->d_chunks, chunks.data(), chunks.size())) ||
+        (rc = upload(c, &c->d_tok_chunk_off, tok_chunk_off.data(), tok_chunk_off.size())))
+        return rc;
+    if (m > 0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_flow), (size_t)m * sizeof(double2)));
+    if (c->n_chunks > 0) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_sums), (size_t)c->n_chunks * sizeof(double)));
+    return CFMM_OK;
+}
+
 int ensure_geometry(cfmm_ctx* c)
 {
     if (!c->geometry_dirty) return CFMM_OK;
@@ -281,6 +325,10 @@ int ensure_geometry(cfmm_ctx* c)
         HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_lambda), (size_t)trades * sizeof(double2)));
         c->trade_cap = trades;
     }
+    if (global_bins(c)) {
+        int rc = build_incidence(c);
+        if (rc != CFMM_OK) return rc;
+    }
     c->geometry_dirty = false;
     c->have_trades = false;
     c->have_out = false;
@@ -305,7 +353,6 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool timed = c->opt_time_kernels != 0 && c->pending.size() < (1u << 20); // harvest with cfmm_kernel_times
     const bool gb = global_bins(c);
     HIP_TRY(c, hipSetDevice(c->device));
-    if (gb) HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)c->n * sizeof(double), c->stream));
     for (const Group& g : c->groups) {
         SweepArgs a;
         a.v = d_v;
@@ -315,7 +362,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.m = 0;
         a.Delta = a.Lambda = nullptr;
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
-        a.gbins = gb ? d_out : nullptr;
+        a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -330,6 +377,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             std::memset(&ma, 0, sizeof ma);
             ma.nseg = g.nseg;
             ma.common = a;
+            ma.common.gflow = gb ? c->d_flow : nullptr; // mode flag for the launcher; per-segment bases below
             for (int k = 0; k < g.nseg; ++k) {
                 const Segment& s = c->segs[(size_t)g.first + k];
                 MultiSeg& ms = ma.seg[k];
@@ -337,6 +385,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.m = s.m;
                 ms.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
                 ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+                ms.gflow = gb ? c->d_flow + s.trade_off : nullptr;
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
@@ -349,6 +398,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.m = s.m;
             a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+            a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
             LaunchCfg cfg{g.block, g.grid, s.unroll, lds};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
@@ -373,8 +423,14 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (ra && rb) HIP_TRY(c, hipEventRecord(ra, c->stream));
     }
     if (c->rows_total > 0) {
-        hipError_t e = gb ? launch_reduce(c->d_partials, (int)c->rows_total, 1, d_out + c->n, c->stream)
-                          : launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
+        hipError_t e;
+        if (gb) { // pull Ψ per token over the incidence list, then fold the dual-scalar column
+            e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
+                              c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->stream);
+            if (e == hipSuccess) e = launch_reduce(c->d_partials, (int)c->rows_total, 1, d_out + c->n, c->stream);
+        } else {
+            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
+        }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
@@ -428,9 +484,10 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
     return CFMM_OK;
 }
 
-int add_segment_common(cfmm_ctx* c, Segment&& s)
+int add_segment_common(cfmm_ctx* c, Segment&& s, const int32_t* Ai)
 {
-    c->segs.push_back(s);
+    if (global_bins(c) && s.m > 0) s.h_ai.assign(Ai, Ai + 2 * s.m);
+    c->segs.push_back(std::move(s));
     c->geometry_dirty = true;
     c->have_out = false;
     c->have_trades = false;
@@ -511,6 +568,8 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials);
     (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
+    (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
+    (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -588,7 +647,7 @@ int cfmm_pools_add_product(cfmm_ctx* c, int64_t m, const double* R, const double
         free_segment(s);
         return rc;
     }
-    return add_segment_common(c, std::move(s));
+    return add_segment_common(c, std::move(s), Ai);
 }
 
 int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double* w, const double* gamma,
@@ -618,7 +677,7 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
         free_segment(s);
         return rc;
     }
-    return add_segment_common(c, std::move(s));
+    return add_segment_common(c, std::move(s), Ai);
 }
 
 int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, const double* gamma,
@@ -735,7 +794,7 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
         free_segment(s);
         return rc;
     }
-    return add_segment_common(c, std::move(s));
+    return add_segment_common(c, std::move(s), Ai);
 }
 
 int cfmm_pools_clear(cfmm_ctx* c)

@@ -14,7 +14,8 @@ constexpr int kResidentThreads = 2048 * 256; // grid cap for the fat blocks: one
 constexpr int kReduceBlock = 1024;
 constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
 constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 KiB LDS of a CU;
-                                     // larger markets use global bins (sweep_body<..., GBINS=true>)
+                                     // larger markets pull Ψ per token (sweep_body<..., GBINS=true>)
+constexpr int kGatherChunk = 512;    // incidence entries per wavefront in gather_chunks
 
 // SoA-of-pairs pool stores, one struct per pool family.  All pointers are device pointers.
 struct ProductPools {            // src/cfmms.jl:101-111
@@ -53,7 +54,7 @@ struct SweepArgs {
     double2* Delta;              // [m] segment base, may be null when !materialize
     double2* Lambda;
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
-    double* gbins;               // null: LDS bins; else the global Ψ vector flows are added to
+    double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int nt_stores;               // use non-temporal stores for Delta/Lambda
 };
 
@@ -70,6 +71,7 @@ struct MultiSeg {
     AnyPools pools;
     double2* Delta;
     double2* Lambda;
+    double2* gflow;
 };
 struct MultiArgs {
     int nseg;
@@ -94,6 +96,11 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
 // grid must be a multiple of ma.nseg: block b sweeps segment b % nseg and writes partial row b.
 hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool materialize,
                         hipStream_t s);
+
+// Large markets: chunk_sums[c] = sum of flow[entries[chunks[c].x .. chunks[c].y)], then
+// out[t] = sum of chunk_sums[tok_chunk_off[t] .. tok_chunk_off[t+1]) for t < n.
+hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
+                         const int* tok_chunk_off, double* out, int n, hipStream_t s);
 
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s);

@@ -312,10 +312,11 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 
 // One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
 // partial row goes to partials[row].
-// GBINS = true is the large-market mode (n_tokens > kMaxLdsTokens): v is gathered straight from
-// global memory (it stays L2-resident) and flows are added to ONE global Ψ vector with
-// global_atomic_add_f64 -- with that many tokens the same-address contention that rules
-// global atomics out for small n is gone.  The partial rows then carry only the dual scalar.
+// GBINS = true is the large-market mode (n_tokens > kMaxLdsTokens, v and the bins no longer fit
+// LDS): v is gathered straight from global memory (it stays L2-resident) and every pool's two
+// flows Λ−Δ are written to a flow array; Ψ is then PULLED per token over a token -> (pool, side)
+// incidence list built at upload (gather_chunks / token_fold below) -- no float atomics, fixed
+// summation order.  The partial rows carry only the dual scalar.
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
@@ -349,8 +350,7 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
         const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
         if constexpr (GBINS) {
-            if (f1 != 0.0) atomicAdd(&a.gbins[tok.x], f1);   // global_atomic_add_f64
-            if (f2 != 0.0) atomicAdd(&a.gbins[tok.y], f2);
+            a.gflow[i] = make_double2(f1, f2);
         } else {
             if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
             if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
@@ -439,6 +439,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.m = sg.m;
     a.Delta = sg.Delta;
     a.Lambda = sg.Lambda;
+    a.gflow = sg.gflow;
     switch (sg.kind) {
     case 0:
         sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
@@ -493,6 +494,45 @@ __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __
     }
 }
 
+// Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat
+// indices 2·pool + side of the flows that belong to the token; it is cut into chunks of at most
+// kGatherChunk entries so that hub tokens (a numeraire with 10⁵ pools) are spread over many
+// wavefronts.  One wavefront per chunk: lane-strided partial sums, then a fixed shuffle tree.
+__global__ __launch_bounds__(256) void gather_chunks(const int2* __restrict__ chunks, const int* __restrict__ entries,
+                                                     const double* __restrict__ flow, double* __restrict__ chunk_sums,
+                                                     int n_chunks)
+{
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_chunks) return;
+    const int2 ch = chunks[wave];
+    double s = 0.0;
+    for (int e = ch.x + lane; e < ch.y; e += 64) s += flow[entries[e]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) chunk_sums[wave] = s;
+}
+
+// out[t] = sum of token t's chunk sums, in chunk order.
+__global__ __launch_bounds__(256) void token_fold(const int* __restrict__ tok_chunk_off,
+                                                  const double* __restrict__ chunk_sums, double* __restrict__ out, int n)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (int c = tok_chunk_off[t]; c < tok_chunk_off[t + 1]; ++c) s += chunk_sums[c];
+    out[t] = s;
+}
+
+hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
+                         const int* tok_chunk_off, double* out, int n, hipStream_t s)
+{
+    if (n_chunks > 0)
+        hipLaunchKernelGGL(gather_chunks, dim3((n_chunks + 3) / 4), dim3(256), 0, s, chunks, entries, flow, chunk_sums,
+                           n_chunks);
+    hipLaunchKernelGGL(token_fold, dim3((n + 255) / 256), dim3(256), 0, s, tok_chunk_off, chunk_sums, out, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -522,7 +562,7 @@ template <int B>
 static void launch_multi_b(const MultiArgs& ma, int grid, size_t lds_bytes, bool mat, hipStream_t s)
 {
     dim3 g(grid), b(B);
-    if (ma.common.gbins) {
+    if (ma.common.gflow) {
         if (mat) hipLaunchKernelGGL((sweep_multi<true, B, true>), g, b, lds_bytes, s, ma);
         else hipLaunchKernelGGL((sweep_multi<false, B, true>), g, b, lds_bytes, s, ma);
     } else {
@@ -562,7 +602,7 @@ template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid), b(B);
-    if (a.gbins) { // large-market mode, one pool per lane per tile only
+    if (a.gflow) { // large-market mode, one pool per lane per tile only
         if (mat) hipLaunchKernelGGL((sweep_kernel<Ops, true, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
         else hipLaunchKernelGGL((sweep_kernel<Ops, false, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
         return;

@@ -325,6 +325,24 @@ def test_large_market_global_bins(n):
         assert abs(acc - acco) <= 1e-11 * max(abs(acco), 1.0)
     psi2 = device_sweep(segs, n, v, materialize=False)[2]
     assert rel_to_max(psi2, psio) <= 1e-12
+    np.testing.assert_array_equal(psi2, psi)      # pull-based gather: fixed summation order, reproducible
+
+
+def test_large_market_hub_token():
+    """a numeraire that sits in every pool (degree = m): its incidence list is cut into many chunks"""
+    n, m = 9000, 200_000
+    rng = np.random.default_rng(3)
+    other = rng.integers(2, n + 1, m)
+    Ai = np.stack([np.ones(m, dtype=np.int64), other], 1)
+    flip = rng.random(m) < 0.5
+    Ai[flip] = Ai[flip][:, ::-1]
+    b = cr.ProductTwoCoin.batch(1000 * rng.random((m, 2)) + 1, rng.choice([0.997, 1.0], m), Ai)
+    v = synth.sweep_prices(n, seed=1, spread=0.3)
+    D, L, psi, acc = device_sweep([b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    assert rel_to_max(psi, psio) <= 1e-12
+    assert abs(psi[0] - psio[0]) <= 1e-11 * abs(psio[0])
 
 
 def test_contexts_with_different_token_counts_coexist():
