@@ -426,8 +426,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         hipError_t e;
         if (gb) { // pull Ψ per token over the incidence list, then fold the dual-scalar column
             e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
-                              c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->stream);
-            if (e == hipSuccess) e = launch_reduce(c->d_partials, (int)c->rows_total, 1, d_out + c->n, c->stream);
+                              c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->d_partials, (int)c->rows_total, c->stream);
         } else {
             e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
         }

@@ -98,9 +98,10 @@ hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_byt
                         hipStream_t s);
 
 // Large markets: chunk_sums[c] = sum of flow[entries[chunks[c].x .. chunks[c].y)], then
-// out[t] = sum of chunk_sums[tok_chunk_off[t] .. tok_chunk_off[t+1]) for t < n.
+// out[t] = sum of chunk_sums[tok_chunk_off[t] .. tok_chunk_off[t+1]) for t < n and
+// out[n] = sum of acc_rows[0 .. rows) (the dual-scalar column of the partial rows).
 hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
-                         const int* tok_chunk_off, double* out, int n, hipStream_t s);
+                         const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s);
 
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s);

@@ -502,34 +502,53 @@ __global__ __launch_bounds__(256) void gather_chunks(const int2* __restrict__ ch
                                                      const double* __restrict__ flow, double* __restrict__ chunk_sums,
                                                      int n_chunks)
 {
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_chunks) return;
-    const int2 ch = chunks[wave];
+    // 16 lanes per chunk (4 chunks per wavefront): a typical token has a few dozen incident
+    // pools, so a full wavefront per chunk would idle most lanes and be latency-bound
+    constexpr int kGroup = 16;
+    const int chunk = (blockIdx.x * 256 + threadIdx.x) / kGroup, lane = threadIdx.x % kGroup;
     double s = 0.0;
-    for (int e = ch.x + lane; e < ch.y; e += 64) s += flow[entries[e]];
+    if (chunk < n_chunks) {
+        const int2 ch = chunks[chunk];
+        for (int e = ch.x + lane; e < ch.y; e += kGroup) s += flow[entries[e]];
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) chunk_sums[wave] = s;
+    for (int off = kGroup / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kGroup);
+    if (lane == 0 && chunk < n_chunks) chunk_sums[chunk] = s;
 }
 
-// out[t] = sum of token t's chunk sums, in chunk order.
+// out[t] = sum of token t's chunk sums, in chunk order (t < n); the block after the last token
+// block folds the dual-scalar column of the partial rows into out[n] (lane-strided, fixed tree).
 __global__ __launch_bounds__(256) void token_fold(const int* __restrict__ tok_chunk_off,
-                                                  const double* __restrict__ chunk_sums, double* __restrict__ out, int n)
+                                                  const double* __restrict__ chunk_sums, double* __restrict__ out, int n,
+                                                  const double* __restrict__ acc_rows, int rows)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
+    const int token_blocks = (n + 255) / 256;
+    if ((int)blockIdx.x < token_blocks) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        if (t >= n) return;
+        double s = 0.0;
+        for (int c = tok_chunk_off[t]; c < tok_chunk_off[t + 1]; ++c) s += chunk_sums[c];
+        out[t] = s;
+        return;
+    }
+    __shared__ double wsum[4];
     double s = 0.0;
-    for (int c = tok_chunk_off[t]; c < tok_chunk_off[t + 1]; ++c) s += chunk_sums[c];
-    out[t] = s;
+    for (int r = threadIdx.x; r < rows; r += 256) s += acc_rows[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
 hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
-                         const int* tok_chunk_off, double* out, int n, hipStream_t s)
+                         const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s)
 {
     if (n_chunks > 0)
-        hipLaunchKernelGGL(gather_chunks, dim3((n_chunks + 3) / 4), dim3(256), 0, s, chunks, entries, flow, chunk_sums,
+        hipLaunchKernelGGL(gather_chunks, dim3((n_chunks + 15) / 16), dim3(256), 0, s, chunks, entries, flow, chunk_sums,
                            n_chunks);
-    hipLaunchKernelGGL(token_fold, dim3((n + 255) / 256), dim3(256), 0, s, tok_chunk_off, chunk_sums, out, n);
+    hipLaunchKernelGGL(token_fold, dim3((n + 255) / 256 + 1), dim3(256), 0, s, tok_chunk_off, chunk_sums, out, n,
+                       acc_rows, rows);
     return hipGetLastError();
 }
 
