@@ -182,6 +182,15 @@ int check_two_coin(cfmm_ctx* c, int64_t m, const double* R, const double* gamma,
     return CFMM_OK;
 }
 
+// Grid cap for the fat (512/1024-thread) blocks: a full machine of resident threads while the
+// partial rows are short; half of that (one 1024-thread block per CU) once a row is long enough
+// (n_tokens > 1024) for rows x n_tokens to dominate the fold kernel (measured at n = 4096:
+// fold 10.5 us at 512 rows, 7.8 us at 256; sweep time equal).
+int fat_grid_cap(const cfmm_ctx* c, int block)
+{
+    return (c->n > 1024 && c->n <= kMaxLdsTokens ? kResidentThreads / 2 : kResidentThreads) / block;
+}
+
 // Launch geometry for a segment of m pools.  Small markets: 256-thread blocks, one tile each
 // (enough blocks to cover 256 CUs).  Large markets: 1024-thread blocks, at most two per CU, each
 // striding over many tiles -- this keeps the number of partial rows (and the fold kernel) small.
@@ -201,7 +210,7 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
     } else {
         s.block = c->opt_block == kMidBlock ? kMidBlock : kBigBlock;
         const int64_t tiles = std::max<int64_t>(1, (s.m + (int64_t)s.block * U - 1) / ((int64_t)s.block * U));
-        s.grid = (int)std::min<int64_t>(tiles, c->opt_max_grid > 0 ? c->opt_max_grid : kResidentThreads / s.block);
+        s.grid = (int)std::min<int64_t>(tiles, c->opt_max_grid > 0 ? c->opt_max_grid : fat_grid_cap(c, s.block));
     }
 }
 
@@ -286,7 +295,7 @@ int ensure_geometry(cfmm_ctx* c)
                 tiles = std::max<int64_t>(tiles, (sg.m + block - 1) / block);
             }
             const int64_t cap = std::max<int64_t>(
-                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kSmallBlock ? 2048 : kResidentThreads / block)) / g.nseg);
+                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kSmallBlock ? 2048 : fat_grid_cap(c, block))) / g.nseg);
             const int per_seg = (int)std::min<int64_t>(tiles, cap);
             for (int k = 0; k < g.nseg; ++k) c->segs[first + k].grid = per_seg;
             g.grid = per_seg * g.nseg;
