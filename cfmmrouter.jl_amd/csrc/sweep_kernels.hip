@@ -45,6 +45,7 @@ __device__ __forceinline__ double max0(double x)
 // ProductTwoCoin -- src/cfmms.jl:125-140
 // ---------------------------------------------------------------------------------------------
 struct ProductOps {
+    static constexpr bool kWaveCooperative = false;
     struct Raw {
         double2 R;
         double g;
@@ -111,6 +112,7 @@ __device__ __forceinline__ double geom_arb_lambda(double m, double r1, double r2
 }
 
 struct GeoMeanOps {
+    static constexpr bool kWaveCooperative = false;
     struct Raw {
         double2 R, w;
         double g;
@@ -163,6 +165,7 @@ struct GeoMeanOps {
 // agree with the reference-order forms to ~1e-15 of the reserve scale (asserted at 1e-12 in
 // tests/test_gpu_parity.py); unlike r2^η in the reference, nothing here can overflow.
 struct GeoMeanLogOps {
+    static constexpr bool kWaveCooperative = false;
     struct Raw {
         double2 R, ew, lR;
         double g;
@@ -232,6 +235,7 @@ struct GeoMeanLogOps {
 // current tick (the common case; every BoundedProduct pool) touches only coalesced per-pool
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
+    static constexpr bool kWaveCooperative = true;
     struct Raw {
         double2 pg, ca, cb;
         double cc;
@@ -246,54 +250,105 @@ struct UniV3Ops {
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
 
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    // find_arb_pos (:321-337) on one prepared walk-list entry
+    __device__ __forceinline__ void list_tick(int e, double price, double& d, double& l) const
     {
-        const double cp = r.pg.x, g = r.pg.y;
-        const double pr = v1 / v2;                                     // :340
+        const double2 ks = p.ks[e];
+        const double dd = sqrt(ks.x / price) - ks.y;               // :323
+        d = 0.0;
+        l = 0.0;                                                   // :325-327
+        if (dd > 0) {
+            const double2 dt = p.dt[e];
+            if (dd >= dt.x) {                                      // :330-332
+                d = dt.x;
+                l = p.rout[e];
+            } else {
+                l = dt.y - sqrt(price * ks.x);                     // :334
+                d = dd;
+            }
+        }
+    }
+
+    // One lane per pool for the current tick and the first kLocalTicks ticks beyond it (that is
+    // where almost every walk ends); a pool whose walk goes deeper is then finished by the WHOLE
+    // wavefront: 64 ticks are evaluated at once (each tick's (δ, λ) depends only on the price), a
+    // ballot finds the first tick that stops the walk (:363-365), and the owning lane adds the
+    // ticks before it in walk order (v_readlane), so the sums keep the reference's rounding.
+    // All 64 lanes must call this together (`valid` = this lane holds a pool).
+    static constexpr int kLocalTicks = 2;
+    __device__ __forceinline__ void solve_wave(const Raw& r, bool valid, double v1, double v2, Trade& t) const
+    {
+        const int lane = threadIdx.x & 63;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
-        const bool up = pr < g * cp;                                   // :351
-        const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
-        double sd = 0.0, sl = 0.0;
-        // current tick: `initial` is true here unless the tick is empty (:355-358), so no break test
-        const double k0 = r.ca.x;
-        if (k0 != 0) {
-            const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
-            const double dmax = up ? r.cb.y : r.cc;
-            const double dd = sqrt(k0 / price) - s_in;                 // :323
-            if (dd > 0) {                                              // :325-327
-                if (dd >= dmax) {                                      // :330-332
-                    const double2 R = p.curR[r.i];
-                    sd = dmax;
-                    sl = up ? R.y : R.x;
-                } else {
-                    sl = s_out - sqrt(price * k0);                     // :334
-                    sd = dd;
+        bool trades = false, up = false, pending = false;
+        double g = 1.0, price = 1.0, sd = 0.0, sl = 0.0;
+        int next = 0, remaining = 0;                                   // walk-list cursor of this lane's pool
+        if (valid) {
+            const double cp = r.pg.x;
+            g = r.pg.y;
+            const double pr = v1 / v2;                                 // :340
+            if (!(g * cp <= pr && pr <= cp / g)) {                     // :347-349
+                trades = true;
+                up = pr < g * cp;                                      // :351
+                price = up ? pr / g : 1.0 / (g * pr);                  // :361 / :381
+                // current tick: `initial` is true here unless the tick is empty (:355-358): no break test
+                const double k0 = r.ca.x;
+                if (k0 != 0) {
+                    const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
+                    const double dmax = up ? r.cb.y : r.cc;
+                    const double dd = sqrt(k0 / price) - s_in;         // :323
+                    if (dd > 0) {                                      // :325-327
+                        if (dd >= dmax) {                              // :330-332
+                            const double2 R = p.curR[r.i];
+                            sd = dmax;
+                            sl = up ? R.y : R.x;
+                        } else {
+                            sl = s_out - sqrt(price * k0);             // :334
+                            sd = dd;
+                        }
+                    }
                 }
+                next = up ? r.walk.x : r.walk.z;
+                remaining = up ? r.walk.y : r.walk.w;
+                bool stopped = false;
+                for (int j = 0; j < kLocalTicks && remaining > 0; ++j) {   // :353 / :375, empty ticks elided
+                    double d, l;
+                    list_tick(next, price, d, l);
+                    if (d == 0 || l == 0) { stopped = true; break; }   // :363-365 (initial is false here)
+                    sd += d;
+                    sl += l;
+                    ++next;
+                    --remaining;
+                }
+                pending = !stopped && remaining > 0;
             }
         }
-        const int begin = up ? r.walk.x : r.walk.z;
-        const int count = up ? r.walk.y : r.walk.w;
-        for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
-            const double2 ks = p.ks[begin + j];
-            const double dd = sqrt(ks.x / price) - ks.y;               // :323
-            double d = 0.0, l = 0.0;
-            if (dd > 0) {
-                const double2 dt = p.dt[begin + j];
-                if (dd >= dt.x) {
-                    d = dt.x;
-                    l = p.rout[begin + j];
-                } else {
-                    l = dt.y - sqrt(price * ks.x);
-                    d = dd;
+        unsigned long long todo = __ballot(pending);
+        while (todo) {                                                 // deep walks: one pool at a time, 64 ticks at once
+            const int src = __ffsll((long long)todo) - 1;
+            const int first = __shfl(next, src, 64), count = __shfl(remaining, src, 64);
+            const double pr_src = __shfl(price, src, 64);
+            bool stopped = false;
+            for (int base = 0; base < count && !stopped; base += 64) {
+                const int idx = base + lane;
+                const bool in = idx < count;
+                double d = 0.0, l = 0.0;
+                if (in) list_tick(first + idx, pr_src, d, l);
+                const unsigned long long stop = __ballot(in && (d == 0 || l == 0));
+                const int batch = count - base < 64 ? count - base : 64;
+                const int upto = stop ? __ffsll((long long)stop) - 1 : batch;
+                for (int k = 0; k < upto; ++k) {                       // walk order, owner lane accumulates
+                    const double dk = __shfl(d, k, 64), lk = __shfl(l, k, 64);
+                    if (lane == src) { sd += dk; sl += lk; }
                 }
+                stopped = stop != 0;
             }
-            if (d == 0 || l == 0) break;                               // :363-365 (initial is false here)
-            sd += d;
-            sl += l;
+            todo &= todo - 1;
         }
-        if (up) { t.d1 = sd / g; t.l2 = sl; }                          // :366-372
-        else { t.d2 = sd / g; t.l1 = sl; }                             // :386-391
+        if (trades) {
+            if (up) { t.d1 = sd / g; t.l2 = sl; }                      // :366-372
+            else { t.d2 = sd / g; t.l1 = sl; }                         // :386-391
+        }
     }
 };
 
@@ -334,13 +389,18 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     double* my_bins = bins + (size_t)(a.copies == 1 ? 0 : wave) * a.n_pad;
     double acc = 0.0;
 
-    auto process = [&](const typename Ops::Raw& raw, int64_t i) {
-        const int2 tok = ops.tokens(raw);
+    // `valid` is false only for wave-cooperative families, whose lanes without a pool still have to
+    // take part in the wavefront-wide phases of solve_wave.
+    auto process = [&](const typename Ops::Raw& raw, int64_t i, bool valid) {
+        int2 tok = make_int2(0, 0);
+        if (valid) tok = ops.tokens(raw);
         double v1, v2;                                   // v[r.cfmms[i].Ai]
         if constexpr (GBINS) { v1 = a.v[tok.x]; v2 = a.v[tok.y]; }
         else { v1 = v_lds[tok.x]; v2 = v_lds[tok.y]; }
         Trade t;
-        ops.solve(raw, v1, v2, t);
+        if constexpr (Ops::kWaveCooperative) ops.solve_wave(raw, valid, v1, v2, t);
+        else ops.solve(raw, v1, v2, t);
+        if (!valid) return;
         if (MAT) {
             store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
             store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
@@ -365,17 +425,28 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         // registers only cost occupancy.)
         const int64_t stride = (int64_t)nblocks * kBlock;
         int64_t i = (int64_t)bid * kBlock + tid;
-        typename Ops::Raw cur;
+        typename Ops::Raw cur = {};
         bool ok = i < a.m;
         if (ok) cur = ops.load(i);
         for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
         for (int j = tid; j < n_zero; j += kBlock) bins[j] = 0.0;
         __syncthreads();
-        while (ok) {
-            process(cur, i);
-            i += stride;
-            ok = i < a.m;
-            if (ok) cur = ops.load(i);
+        if constexpr (Ops::kWaveCooperative) {
+            while (__any(ok)) {                          // the wavefront stays together
+                process(cur, i, ok);
+                if (ok) {
+                    i += stride;
+                    ok = i < a.m;
+                    if (ok) cur = ops.load(i);
+                }
+            }
+        } else {
+            while (ok) {
+                process(cur, i, true);
+                i += stride;
+                ok = i < a.m;
+                if (ok) cur = ops.load(i);
+            }
         }
     } else {
         for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
@@ -383,9 +454,9 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         __syncthreads();
         const int64_t tile_pools = (int64_t)kBlock * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {
+        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {   // block-uniform trip count
             const int64_t base = tile * tile_pools + tid;
-            typename Ops::Raw raw[U];
+            typename Ops::Raw raw[U] = {};
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -395,7 +466,7 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) process(raw[u], base + (int64_t)u * kBlock);
+                if (Ops::kWaveCooperative || ok[u]) process(raw[u], base + (int64_t)u * kBlock, ok[u]);
         }
     }
 

@@ -141,6 +141,26 @@ def test_univ3_bit_exact_ragged_and_degenerate():
         assert rel_to_max(psi, psio) <= 1e-11
 
 
+@pytest.mark.parametrize("t", [3, 64, 65, 200])
+def test_univ3_deep_walks_wave_cooperative(t):
+    """Ladders of t ticks with the external price far outside: walks cross up to ~t ticks, i.e. the
+    wavefront-cooperative phase (64 ticks per step) runs for 0, 1 and several batches.  Bit-exact."""
+    m, n = 3000, 8
+    b = synth.univ3_pools(m, n, t, seed=t)
+    for spread in (0.3, 8.0):                       # e^±8: every pool is drained in one direction
+        v = synth.sweep_prices(n, seed=t, spread=spread)
+        D, L, psi, acc = device_sweep([b], n, v)
+        Do, Lo, psio, acco = oracle_sweep([b], n, v)
+        np.testing.assert_array_equal(D, Do)
+        np.testing.assert_array_equal(L, Lo)
+        assert rel_to_max(psi, psio) <= 1e-11
+    # mixed launch (sweep_multi) exercises the same cooperative code next to lane-per-pool families
+    D, L, psi, acc = device_sweep([synth.product_pools(5000, n, 1), b], n, v)
+    Do, Lo, psio, acco = oracle_sweep([synth.product_pools(5000, n, 1), b], n, v)
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+
+
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 @pytest.mark.parametrize("copies", [1, 2])
 @pytest.mark.parametrize("block", [256, 512, 1024])
