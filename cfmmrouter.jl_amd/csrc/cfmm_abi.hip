@@ -30,6 +30,7 @@ struct Segment {
     int64_t m = 0;
     int64_t trade_off = 0; // first row of this segment in the trade buffers
     int64_t n_ticks_total = 0;
+    int deep = 0; // univ3: longest walk list exceeds kDeepWalk -> wavefront-cooperative kernel
     // device arrays (owned)
     double2* R = nullptr;
     double2* w = nullptr;
@@ -398,7 +399,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
-                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, s.deep}; break;
                 }
             }
             e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
@@ -415,7 +416,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
-                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout}, a, cfg, materialize, c->stream);
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, s.deep}, a, cfg, materialize, c->stream);
                 break;
             }
         }
@@ -702,6 +703,7 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
     std::vector<double> rout, cur_c((size_t)m);
     std::vector<int4> walk((size_t)m);
+    int longest = 0;
     ks.reserve((size_t)T + (size_t)m);
     dt.reserve((size_t)T + (size_t)m);
     rout.reserve((size_t)T + (size_t)m);
@@ -785,6 +787,7 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
             ++cnt;
         }
         w.w = cnt;
+        longest = std::max(longest, std::max(w.y, w.w));
         walk[(size_t)i] = w;
         pg[(size_t)i] = make_double2(cp, gamma[i]);
     }
@@ -793,6 +796,7 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     s.kind = CFMM_KIND_UNIV3;
     s.m = m;
     s.n_ticks_total = T;
+    s.deep = longest > 8 ? 1 : 0; // short ladders: a lane walks its own pool; long: the wavefront helps
     int rc;
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
         (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||

@@ -43,6 +43,7 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     const double2* ks;           // [W] {k, R_in + alpha_in}
     const double2* dt;           // [W] {delta_max, R_out + beta_out}
     const double* rout;          // [W] R_out
+    int deep;                    // 1: some walk list is long -> wavefront-cooperative kernel (UniV3CoopOps)
 };
 
 struct SweepArgs {

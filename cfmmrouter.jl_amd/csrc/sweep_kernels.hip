@@ -235,7 +235,7 @@ struct GeoMeanLogOps {
 // current tick (the common case; every BoundedProduct pool) touches only coalesced per-pool
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
-    static constexpr bool kWaveCooperative = true;
+    static constexpr bool kWaveCooperative = false;
     struct Raw {
         double2 pg, ca, cb;
         double cc;
@@ -268,6 +268,51 @@ struct UniV3Ops {
             }
         }
     }
+
+    // Lane-per-pool walk (segments whose walk lists are short, e.g. every BoundedProduct pool).
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    {
+        const double cp = r.pg.x, g = r.pg.y;
+        const double pr = v1 / v2;                                     // :340
+        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
+        const bool up = pr < g * cp;                                   // :351
+        const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
+        double sd = 0.0, sl = 0.0;
+        // current tick: `initial` is true here unless the tick is empty (:355-358), so no break test
+        const double k0 = r.ca.x;
+        if (k0 != 0) {
+            const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
+            const double dmax = up ? r.cb.y : r.cc;
+            const double dd = sqrt(k0 / price) - s_in;                 // :323
+            if (dd > 0) {                                              // :325-327
+                if (dd >= dmax) {                                      // :330-332
+                    const double2 R = p.curR[r.i];
+                    sd = dmax;
+                    sl = up ? R.y : R.x;
+                } else {
+                    sl = s_out - sqrt(price * k0);                     // :334
+                    sd = dd;
+                }
+            }
+        }
+        const int begin = up ? r.walk.x : r.walk.z;
+        const int count = up ? r.walk.y : r.walk.w;
+        for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
+            double d, l;
+            list_tick(begin + j, price, d, l);
+            if (d == 0 || l == 0) break;                               // :363-365 (initial is false here)
+            sd += d;
+            sl += l;
+        }
+        if (up) { t.d1 = sd / g; t.l2 = sl; }                          // :366-372
+        else { t.d2 = sd / g; t.l1 = sl; }                             // :386-391
+    }
+};
+
+// The same family for segments with long walk lists (deep tick ladders).
+struct UniV3CoopOps : UniV3Ops {
+    static constexpr bool kWaveCooperative = true;
 
     // One lane per pool for the current tick and the first kLocalTicks ticks beyond it (that is
     // where almost every walk ends); a pool whose walk goes deeper is then finished by the WHOLE
@@ -519,7 +564,12 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
         break;
     default:
-        sweep_body<UniV3Ops, MAT, 1, BLOCK, GBINS>(UniV3Ops{sg.pools.u}, a, local, nblocks, blockIdx.x);
+        {   // the cooperative variant serves both shallow and deep segments here (no register cost:
+            // the fused kernel's footprint is set by the GeometricMean branch)
+            UniV3CoopOps ops;
+            ops.p = sg.pools.u;
+            sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, blockIdx.x);
+        }
         break;
     }
 }
@@ -685,6 +735,8 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     if (e != hipSuccess) return e;
     e = set_lds_attr<GeoMeanLogOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
+    e = set_lds_attr<UniV3CoopOps>(max_lds_bytes);
+    if (e != hipSuccess) return e;
     return set_lds_attr<UniV3Ops>(max_lds_bytes);
 }
 
@@ -731,7 +783,10 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    return launch_any(UniV3Ops{p}, a, c, mat, s);
+    if (!p.deep) return launch_any(UniV3Ops{p}, a, c, mat, s);
+    UniV3CoopOps ops;
+    ops.p = p;
+    return launch_any(ops, a, c, mat, s);
 }
 
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s)
