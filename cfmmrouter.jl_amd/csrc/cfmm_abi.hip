@@ -107,6 +107,7 @@ struct cfmm_ctx {
     int64_t opt_nt_stores = 0;
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
+    int64_t opt_univ3_coop = -1;   // -1 auto (by walk-list length), 0 lane-per-pool only, 1 wavefront-cooperative
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
     int64_t opt_spin_wait = 0;     // 1: host-pointer calls busy-poll the stream (measured: no gain over hipStreamSynchronize)
 
@@ -399,7 +400,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
-                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, s.deep}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
                 }
             }
             e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
@@ -416,7 +417,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
-                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, s.deep}, a, cfg, materialize, c->stream);
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}, a, cfg, materialize, c->stream);
                 break;
             }
         }
@@ -610,6 +611,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "geomean_exact")) return &c->opt_geomean_exact;
     if (!std::strcmp(key, "fuse_segments")) return &c->opt_fuse_segments;
     if (!std::strcmp(key, "zero_copy")) return &c->opt_zero_copy;
+    if (!std::strcmp(key, "univ3_coop")) return &c->opt_univ3_coop;
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     return nullptr;
 }
