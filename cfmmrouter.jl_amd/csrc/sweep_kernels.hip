@@ -314,13 +314,15 @@ struct UniV3Ops {
 struct UniV3CoopOps : UniV3Ops {
     static constexpr bool kWaveCooperative = true;
 
-    // One lane per pool for the current tick and the first kLocalTicks ticks beyond it (that is
-    // where almost every walk ends); a pool whose walk goes deeper is then finished by the WHOLE
+    // One lane per pool while most lanes of the wavefront are still walking; the last few
+    // stragglers (pools that walk much deeper than their neighbours) are finished by the WHOLE
     // wavefront: 64 ticks are evaluated at once (each tick's (δ, λ) depends only on the price), a
     // ballot finds the first tick that stops the walk (:363-365), and the owning lane adds the
     // ticks before it in walk order (v_readlane), so the sums keep the reference's rounding.
+    // Measured (scripts/deep_walk.py): when EVERY pool of a wavefront walks deep, lane-per-pool is
+    // the faster form (all 64 lanes busy); cooperation pays for the sparse deep walks.
     // All 64 lanes must call this together (`valid` = this lane holds a pool).
-    static constexpr int kLocalTicks = 2;
+    static constexpr int kCoopLanes = 4;   // stragglers left in a wavefront before it finishes them together
     __device__ __forceinline__ void solve_wave(const Raw& r, bool valid, double v1, double v2, Trade& t) const
     {
         const int lane = threadIdx.x & 63;
@@ -355,40 +357,52 @@ struct UniV3CoopOps : UniV3Ops {
                 }
                 next = up ? r.walk.x : r.walk.z;
                 remaining = up ? r.walk.y : r.walk.w;
-                bool stopped = false;
-                for (int j = 0; j < kLocalTicks && remaining > 0; ++j) {   // :353 / :375, empty ticks elided
-                    double d, l;
-                    list_tick(next, price, d, l);
-                    if (d == 0 || l == 0) { stopped = true; break; }   // :363-365 (initial is false here)
+                pending = remaining > 0;
+            }
+        }
+        // Walk the lists in lockstep, one tick per lane per trip, while many lanes are still
+        // walking (that IS the parallel form).  Once only a few stragglers are left -- lanes
+        // whose pools walk much deeper than their neighbours' -- the whole wavefront finishes them:
+        // 64 ticks per step instead of one dependent load after another in an almost empty wave.
+        for (;;) {
+            unsigned long long todo = __ballot(pending);
+            if (!todo) break;
+            if (__popcll(todo) <= kCoopLanes) {
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    const int first = __shfl(next, src, 64), count = __shfl(remaining, src, 64);
+                    const double pr_src = __shfl(price, src, 64);
+                    bool stopped = false;
+                    for (int base = 0; base < count && !stopped; base += 64) {
+                        const int idx = base + lane;
+                        const bool in = idx < count;
+                        double d = 0.0, l = 0.0;
+                        if (in) list_tick(first + idx, pr_src, d, l);
+                        const unsigned long long stop = __ballot(in && (d == 0 || l == 0));
+                        const int batch = count - base < 64 ? count - base : 64;
+                        const int upto = stop ? __ffsll((long long)stop) - 1 : batch;
+                        for (int k = 0; k < upto; ++k) {               // walk order, owner lane accumulates
+                            const double dk = __shfl(d, k, 64), lk = __shfl(l, k, 64);
+                            if (lane == src) { sd += dk; sl += lk; }
+                        }
+                        stopped = stop != 0;
+                    }
+                    todo &= todo - 1;
+                }
+                break;
+            }
+            if (pending) {                                             // :353 / :375, empty ticks elided
+                double d, l;
+                list_tick(next, price, d, l);
+                if (d == 0 || l == 0) {                                // :363-365 (initial is false here)
+                    pending = false;
+                } else {
                     sd += d;
                     sl += l;
                     ++next;
-                    --remaining;
+                    pending = --remaining > 0;
                 }
-                pending = !stopped && remaining > 0;
             }
-        }
-        unsigned long long todo = __ballot(pending);
-        while (todo) {                                                 // deep walks: one pool at a time, 64 ticks at once
-            const int src = __ffsll((long long)todo) - 1;
-            const int first = __shfl(next, src, 64), count = __shfl(remaining, src, 64);
-            const double pr_src = __shfl(price, src, 64);
-            bool stopped = false;
-            for (int base = 0; base < count && !stopped; base += 64) {
-                const int idx = base + lane;
-                const bool in = idx < count;
-                double d = 0.0, l = 0.0;
-                if (in) list_tick(first + idx, pr_src, d, l);
-                const unsigned long long stop = __ballot(in && (d == 0 || l == 0));
-                const int batch = count - base < 64 ? count - base : 64;
-                const int upto = stop ? __ffsll((long long)stop) - 1 : batch;
-                for (int k = 0; k < upto; ++k) {                       // walk order, owner lane accumulates
-                    const double dk = __shfl(d, k, 64), lk = __shfl(l, k, 64);
-                    if (lane == src) { sd += dk; sl += lk; }
-                }
-                stopped = stop != 0;
-            }
-            todo &= todo - 1;
         }
         if (trades) {
             if (up) { t.d1 = sd / g; t.l2 = sl; }                      // :366-372

@@ -5,10 +5,13 @@ import numpy as np, torch
 import cfmmrouter_amd as cr
 from cfmmrouter_amd import synth
 
-for m, t, spread in ((100_000, 200, 8.0), (100_000, 200, 0.5), (100_000, 32, 8.0), (1_000_000, 2, 0.2)):
+for m, t, spread, stragglers in ((100_000, 200, 8.0, False), (100_000, 200, 0.5, False), (100_000, 200, 0.02, True),
+                                 (100_000, 32, 8.0, False), (1_000_000, 2, 0.2, False)):
     n = 64
     b = synth.univ3_pools(m, n, t, seed=1) if t > 2 else synth.bounded_product_pools(m, n, seed=1)
     v = synth.sweep_prices(n, seed=1, spread=spread)
+    if stragglers:            # one token far off: ~3 % of the pools walk their whole ladder, the rest stay put
+        v[0] *= np.exp(8.0)
     be = cr.DeviceBackend(n, [b])
     stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); be.ctx.set_stream(stream.cuda_stream)
     v_t = torch.from_numpy(v).to("cuda"); out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
@@ -24,5 +27,5 @@ for m, t, spread in ((100_000, 200, 8.0), (100_000, 200, 0.5), (100_000, 32, 8.0
         kt = be.ctx.kernel_times(); be.ctx.set_option("time_kernels", 0)
         res[mode] = (1e3 * kt["sweep_ms"] / 20, out_t.cpu().numpy().copy())
     same = np.array_equal(res[0][1], res[1][1])
-    print(f"m={m} ticks={t} spread={spread}: lane-per-pool {res[0][0]:.1f} us, wave-cooperative {res[1][0]:.1f} us, identical Psi: {same}")
+    print(f"m={m} ticks={t} spread={spread} stragglers={stragglers}: lane-per-pool {res[0][0]:.1f} us, wave-cooperative {res[1][0]:.1f} us, identical Psi: {same}")
     be.close()
