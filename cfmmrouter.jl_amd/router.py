@@ -48,6 +48,13 @@ class DeviceBackend:
     def trades(self):
         return self.ctx.trades()
 
+    def reload(self, batches):
+        """Replace the device pool store (used after update_reserves_)."""
+        self.ctx.clear()
+        for b in batches:
+            if len(b):
+                _upload(self.ctx, b)
+
     def close(self):
         self.ctx.close()
 
@@ -277,6 +284,33 @@ def netflows(r: Router):
 
 
 def update_reserves_(r: Router):
-    """update_reserves!(r) -- src/router.jl:127-132.  The reference calls a per-CFMM method that
-    is defined nowhere (its own test marks it "borked", test/arb.jl:30-39); same here."""
-    raise NotImplementedError("update_reserves! has no per-CFMM method in the reference (MethodError there)")
+    """update_reserves!(r) -- src/router.jl:127-132.
+
+    The reference's router method calls `update_reserves!(c, Δ, Λ, v)` per pool, a method that is
+    defined nowhere (its own test marks it "borked", test/arb.jl:30-39), so there is no reference
+    behaviour to match.  What is implemented here is the update the routing problem itself
+    prescribes (find_arb! docstring, src/cfmms.jl:26-31: the pool ends at R + γΔ − Λ) for the
+    two-coin families; UniV3 pools (whose state is a price and a tick ladder) are not supported.
+    The packed pool store is rebuilt on the device; the trades of the latest sweep are consumed."""
+    if any(b.kind == KIND_UNIV3 for b in r._batches):
+        raise NotImplementedError("update_reserves! is not defined for UniV3 pools (nor in the reference)")
+    if not hasattr(r._backend, "reload"):
+        raise NotImplementedError("this backend cannot reload pools")
+    D, Lm = r._backend.trades()                       # packed (segment) order
+    off = 0
+    for b in r._batches:
+        m = len(b)
+        b.R[:] = b.R + b.γ[:, None] * D[off:off + m] - Lm[off:off + m]
+        off += m
+    r._backend.reload(r._batches)
+    if isinstance(r.cfmms, list):                     # keep the per-pool objects in step
+        it = iter(range(r._m)) if r._order is None else iter(r._order)
+        for b in r._batches:
+            for k in range(len(b)):
+                r.cfmms[next(it)].R[:] = b.R[k]
+    r._Δs = np.zeros((r._m, 2))
+    r._Λs = np.zeros((r._m, 2))
+    r._psi = np.zeros(r.n_tokens)
+    r._acc = 0.0
+    r._trades_stale = False
+    return None

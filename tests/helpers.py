@@ -58,3 +58,6 @@ class OracleBackend:
 
     def trades(self):
         return self.D, self.L
+
+    def reload(self, batches):
+        self.ps = oracle_poolset(batches, self.n_tokens)

@@ -474,6 +474,27 @@ def test_route_native_solver_one_call(kind):
     r.close()
 
 
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+def test_no_fee_optimality_after_update_reserves(solver):
+    """The reference's disabled check_opt_conditions_no_fee! (test/arb.jl:30-39) on the device path:
+    route!, update_reserves!, then ∇φ(R) ∥ v[Ai] for every pool and nothing left to arbitrage."""
+    n, m = 24, 20_000
+    b = synth.product_pools(m, n, seed=42)
+    b.γ[:] = 1.0
+    k0 = b.R[:, 0] * b.R[:, 1]
+    r = cr.Router(cr.LinearNonnegative(synth.linear_prices(n, seed=42)), b, n)
+    cr.route_(r, solver=solver)
+    cr.update_reserves_(r)
+    R = r._batches[0].R
+    vv = r.v[b.Ai - 1]
+    cos = (R[:, 1] * vv[:, 0] + R[:, 0] * vv[:, 1]) / (np.hypot(R[:, 0], R[:, 1]) * np.hypot(vv[:, 0], vv[:, 1]))
+    assert np.max(np.abs(cos - 1.0)) < 1e-9
+    assert np.max(np.abs(R[:, 0] * R[:, 1] - k0) / k0) < 1e-9
+    cr.route_(r, solver=solver)                       # the updated pools sit on the device
+    assert np.max(np.abs(cr.netflows(r))) < 1e-2
+    r.close()
+
+
 # ---- BASELINE-size properties (no oracle at this size inside the timed budget) ---------------------------
 
 def test_full_size_properties():

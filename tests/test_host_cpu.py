@@ -221,8 +221,28 @@ class TestRouteLoopOnOracleBackend:
             np.testing.assert_array_equal(r.Δs[i], D)
             np.testing.assert_array_equal(r.Λs[i], L)
 
-    def test_update_reserves_is_unimplemented_like_upstream(self):
-        r = oracle_router(cr.LinearNonnegative(np.ones(2)), [cr.ProductTwoCoin([1, 1], 1, [1, 2])], 2)
+    def test_update_reserves_and_no_fee_optimality(self):
+        """The reference's disabled check_opt_conditions_no_fee! (test/arb.jl:30-39): after route!
+        and update_reserves!, every pool's marginal price ∇φ(R) is parallel to v[Ai] (γ = 1)."""
+        n = 10
+        b = synth.product_pools(100, n, seed=1234)
+        b.γ[:] = 1.0
+        pools = [b[i] for i in range(100)]
+        r = oracle_router(cr.LinearNonnegative(synth.linear_prices(n)), pools, n)
+        cr.route_(r)
+        k0 = np.array([c.R[0] * c.R[1] for c in pools])
+        cr.update_reserves_(r)
+        for c, k in zip(r.cfmms, k0):
+            p = np.array([c.R[1], c.R[0]])                       # ∇φ for ProductTwoCoin, src/cfmms.jl:117-122
+            vv = r.v[c.Ai - 1]
+            assert abs(p @ vv / (np.linalg.norm(p) * np.linalg.norm(vv)) - 1.0) < 1e-9   # cosangle ≈ 1
+            assert abs(c.R[0] * c.R[1] - k) <= 1e-9 * k          # zero fee: the invariant is preserved
+        cr.route_(r)                                             # nothing is left to arbitrage
+        assert np.max(np.abs(cr.netflows(r))) < 1e-3
+
+    def test_update_reserves_unsupported_for_univ3(self):
+        r = oracle_router(cr.LinearNonnegative(np.ones(2)), [cr.UniV3(15.0, [30., 20, 10, 5], [1., 2, 1.5, 0], 1.0, [1, 2])], 2)
+        cr.find_arb_(r, np.array([16.0, 1.0]))
         with pytest.raises(NotImplementedError):
             cr.update_reserves_(r)
 
