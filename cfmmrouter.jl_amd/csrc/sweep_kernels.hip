@@ -2,12 +2,13 @@
 // sweep of CFMMRouter.jl and the reductions route! consumes.
 //
 // What is replaced (paths relative to the reference root):
-//   find_arb!(r::Router, v)            src/router.jl:38-42    -> sweep_kernel<...>
-//   find_arb!(.., ::ProductTwoCoin)    src/cfmms.jl:125-140   -> ProductPools::solve
-//   find_arb!(.., ::GeometricMeanTwoCoin) src/cfmms.jl:180-196 -> GeoMeanPools::solve
-//   find_arb!(.., ::UniV3) + helpers   src/cfmms.jl:294-395   -> UniV3Pools::solve
+//   find_arb!(r::Router, v)            src/router.jl:38-42    -> sweep_kernel / sweep_multi (sweep_body)
+//   find_arb!(.., ::ProductTwoCoin)    src/cfmms.jl:125-140   -> ProductOps::solve
+//   find_arb!(.., ::GeometricMeanTwoCoin) src/cfmms.jl:180-196 -> GeoMeanLogOps::solve (default), GeoMeanOps::solve
+//   find_arb!(.., ::UniV3) + helpers   src/cfmms.jl:294-395   -> UniV3Ops::solve, UniV3CoopOps::solve_wave
 //   acc loop of fn                     src/router.jl:79-83    -> per-lane acc + wave shuffles
 //   scatter loop of g! / netflows!     src/router.jl:98-100, :111-119 -> LDS bins + reduce_partials
+//                                      (n_tokens > 8192: flow array + gather_chunks / token_fold)
 //
 // Mapping to the machine.  A two-coin closed form is ~25 dependent flops with no parallelism
 // inside a pool, so the unit of work is ONE LANE PER POOL (64 pools per wavefront); the
@@ -23,8 +24,10 @@
 // Numerics.  Everything is binary64.  This translation unit is compiled with
 // -ffp-contract=off and the expressions keep the reference's operation order; with IEEE
 // correctly-rounded / and sqrt the ProductTwoCoin and UniV3 trades are bit-identical to the
-// reference arithmetic.  pow() is the device library's, so GeometricMeanTwoCoin agrees to
-// a few ulp.  HBM-bound by design: no MFMA (there is no contraction anywhere on this path).
+// reference arithmetic (everything v-independent in the UniV3 forms is prepared at upload with the
+// same IEEE operations).  GeometricMeanTwoCoin is evaluated in log space by default (~1e-15 of
+// the reserve scale from the reference's pow forms; GeoMeanOps keeps those, with the device
+// library's pow).  HBM-bound by design: no MFMA (there is no contraction anywhere on this path).
 
 #include "sweep.h"
 
@@ -209,19 +212,6 @@ struct GeoMeanLogOps {
 // ---------------------------------------------------------------------------------------------
 // UniV3 / BoundedProduct -- src/cfmms.jl:294-395 (lane per pool, serial tick walk)
 // ---------------------------------------------------------------------------------------------
-// find_arb_pos(t, price) -- src/cfmms.jl:321-337, on BoundedProduct(k, a, b, R1, R2)
-[[maybe_unused]] __device__ __forceinline__ void find_arb_pos(double k, double a, double b, double R1, double R2,
-                                             double price, double& d, double& l)
-{
-    const double s = R1 + a;
-    const double dd = sqrt(k / price) - s;     // :323
-    if (dd <= 0) { d = 0.0; l = 0.0; return; } // :325-327
-    const double dmax = k / b - s;             // :329 (b == 0 -> Inf)
-    if (dd >= dmax) { d = dmax; l = R2; return; } // :330-332
-    l = (R2 + b) - sqrt(price * k);            // :334
-    d = dd;
-}
-
 // Everything compute_at_tick (:294-313) derives is independent of v, so it is evaluated ONCE at
 // upload (cfmm_abi.hip, same IEEE operations, hence the same bits) into the constants
 // find_arb_pos (:321-337) actually uses:
