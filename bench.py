@@ -180,7 +180,7 @@ def main():
     out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
     materialize = not args.fused
     peer = None
-    if use_dist and not args.rccl:
+    if use_dist and not args.rccl and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
         from cfmmrouter_amd.dist import PeerAllReduce
         peer = PeerAllReduce.create(n + 1, None, torch.device("cuda", local_rank))  # None -> RCCL fallback
 
@@ -225,6 +225,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # sharded runs: the timed path's global {Ψ, acc} against a plain RCCL all-reduce of the local ones
+    collective_check = None
+    if use_dist:
+        step()
+        got = out_t.clone()
+        be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+        ref = out_t.clone()
+        dist.all_reduce(ref)
+        torch.cuda.synchronize()
+        collective_check = float((got - ref).abs().max() / ref.abs().max())
 
     # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):
     # pageable v in, Ψ/acc out over PCIe, one stream sync -- never the headline value
@@ -294,6 +305,8 @@ def main():
                             "second K-step pass; the bracket adds ~2.5 us to each ~10 us kernel vs rocprofv3 "
                             "(profiles/), so frac is a lower bound"},
     }
+    if collective_check is not None:
+        line["collective_check_rel_err"] = collective_check
     if host:
         host["pools_per_s_host_call_find_arb"] = m_rank / (host["find_arb_us"] * 1e-6)
         line["host_boundary"] = host
