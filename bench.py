@@ -285,8 +285,10 @@ def main():
             traffic = None
 
     line = {
-        "metric": "find_arb! pool-evaluations/sec (materialising sweep + Ψ/dual reduction)",
-        "value": value, "unit": "pool-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "find_arb! pools/sec + route! wall-clock, 1M-pool arbitrage, 1/2/4/8 GPU",
+        "value": value, "unit": "pools/s",
+        "value_is": "find_arb! pool-evaluations per second (materialising sweep + Ψ/dual reduction); "
+                    "route! wall-clock is reported under `route`", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
