@@ -518,3 +518,43 @@ def test_full_size_properties():
     Do, Lo = orc.sweep_product(b.R[i], b.γ[i], Ai0[i], v)
     np.testing.assert_array_equal(D[i], Do)
     np.testing.assert_array_equal(L[i], Lo)
+
+
+def test_full_size_properties_config3_and_config5():
+    """BASELINE configs 3 and 5 at full size: size-independent properties + oracle spot rows."""
+    n = 256
+    v = synth.sweep_prices(n, seed=1234)
+    # config 3: 500k ProductTwoCoin + 500k GeometricMeanTwoCoin
+    bp, bg = synth.product_pools(500_000, n, seed=1234), synth.geomean_pools(500_000, n, seed=1234)
+    be = cr.DeviceBackend(n, [bp, bg])
+    psi, acc = be.find_arb(v)
+    D, L = be.trades()
+    be.close()
+    assert np.all(D >= 0) and np.all(L >= 0) and not np.any((D[:, 0] > 0) & (D[:, 1] > 0))
+    Rn = bg.R + bg.γ[:, None] * D[500_000:] - L[500_000:]
+    phi0 = bg.w[:, 0] * np.log(bg.R[:, 0]) + bg.w[:, 1] * np.log(bg.R[:, 1])
+    phi1 = bg.w[:, 0] * np.log(Rn[:, 0]) + bg.w[:, 1] * np.log(Rn[:, 1])
+    assert np.all(phi1 >= phi0 - 1e-11)                     # weighted invariant not decreased
+    Ai0 = np.concatenate([bp.Ai, bg.Ai]).astype(np.int32) - 1
+    assert rel_to_max(psi, orc.netflows(D, L, Ai0, n)) <= REDUCE_TOL
+    profit = (L * v[Ai0]).sum(1) - (D * v[Ai0]).sum(1)
+    assert np.all(profit >= -1e-9) and abs(profit.sum() - acc) <= 1e-9 * acc   # every pool's arbitrage pays; dual scalar
+    i = np.arange(0, 500_000, 991)
+    Dg, Lg = orc.sweep_geomean(bg.R[i], bg.w[i], bg.γ[i], (bg.Ai[i] - 1).astype(np.int32), v)
+    assert np.max(np.abs(D[500_000 + i] - Dg)) <= 1e-9 and np.max(np.abs(L[500_000 + i] - Lg)) <= 1e-9
+    # config 5: 1M BoundedProduct pools (2-tick UniV3)
+    bu = synth.bounded_product_pools(1_000_000, n, seed=1234)
+    be = cr.DeviceBackend(n, [bu])
+    psi, acc = be.find_arb(v)
+    D, L = be.trades()
+    be.close()
+    assert np.all(D >= 0) and np.all(L >= 0) and not np.any((D[:, 0] > 0) & (D[:, 1] > 0))
+    Au = (bu.Ai - 1).astype(np.int32)
+    assert rel_to_max(psi, orc.netflows(D, L, Au, n)) <= REDUCE_TOL
+    i = np.arange(0, 1_000_000, 997)
+    sub = bu.slice(0, 1_000_000)
+    ct = orc.univ3_current_ticks(bu.current_price[i], 2 * np.arange(len(i) + 1), bu.lower_ticks.reshape(-1, 2)[i].reshape(-1))
+    Du, Lu = orc.sweep_univ3(bu.current_price[i], ct, bu.γ[i], Au[i], 2 * np.arange(len(i) + 1),
+                             bu.lower_ticks.reshape(-1, 2)[i].reshape(-1), bu.liquidity.reshape(-1, 2)[i].reshape(-1), v)
+    np.testing.assert_array_equal(D[i], Du)
+    np.testing.assert_array_equal(L[i], Lu)
