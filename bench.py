@@ -237,6 +237,32 @@ def main():
         torch.cuda.synchronize()
         collective_check = float((got - ref).abs().max() / ref.abs().max())
 
+    # sharded route!: every rank drives the same L-BFGS-B on the all-reduced {Ψ, acc} of its own shard
+    route_sharded = None
+    if use_dist:
+        from cfmmrouter_amd import dist as crd
+        obj = objective_for(args.workload, n)
+        v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
+        sr = crd.ShardedRouter(obj, batches, n, device=local_rank, already_sharded=True)
+        cr.route_(sr, v=v0, solver="native")
+        ts = []
+        for _ in range(3):
+            dist.barrier()
+            t0 = time.perf_counter()
+            cr.route_(sr, v=v0, solver="native")
+            ts.append(time.perf_counter() - t0)
+        tmax = torch.tensor([min(ts)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        vchk = torch.from_numpy(sr.v.copy()).to("cuda")
+        vmax, vmin = vchk.clone(), vchk.clone()
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        route_sharded = {"ms": 1e3 * float(tmax.item()), "evaluations": sr.info.get("funcalls"),
+                         "pools_total": world * m_rank, "ranks_agree_on_v": bool(torch.equal(vmax, vmin)),
+                         "max_netflow": float(np.max(np.abs(cr.netflows(sr)))),
+                         "collective": "peer" if sr._backend._peer is not None else "rccl"}
+        sr.close()
+
     # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):
     # pageable v in, Ψ/acc out over PCIe, one stream sync -- never the headline value
     be.ctx.reset_stream()
@@ -309,6 +335,8 @@ def main():
     }
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check
+    if route_sharded is not None:
+        line["route_sharded"] = route_sharded
     if host:
         host["pools_per_s_host_call_find_arb"] = m_rank / (host["find_arb_us"] * 1e-6)
         line["host_boundary"] = host
