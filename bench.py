@@ -260,7 +260,8 @@ def main():
         route_sharded = {"ms": 1e3 * float(tmax.item()), "evaluations": sr.info.get("funcalls"),
                          "pools_total": world * m_rank, "ranks_agree_on_v": bool(torch.equal(vmax, vmin)),
                          "max_netflow": float(np.max(np.abs(cr.netflows(sr)))),
-                         "collective": "peer" if sr._backend._peer is not None else "rccl"}
+                         "collective": ("peer all-reduce inside the library (cfmm_set_peers), route! = one call per rank"
+                                        if isinstance(sr._backend, cr.DeviceBackend) else "rccl via torch.distributed")}
         sr.close()
 
     # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):

@@ -113,6 +113,7 @@ def lib():
                              C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(RouteInfo)]
     L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
                                        C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
+    L.cfmm_set_peers.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64]
     L.cfmm_peer_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_uint64, C.c_void_p]
     L.cfmm_segment_count.argtypes = [_ctx]
@@ -281,6 +282,12 @@ class Context:
                                        int(m), float(factr), float(pgtol), int(maxfun), int(maxiter), ptr(v),
                                        ptr(psi), C.byref(info)))
         return v, psi, info.as_dict()
+
+    def set_peers(self, peer_ptrs, world: int, rank: int, seq: int):
+        """Sharded operation: every host-pointer sweep of this context ends with the one-shot peer
+        all-reduce over the given symmetric buffers (cfmm_set_peers).  world=0 switches it off."""
+        arr = (C.c_uint64 * max(world, 1))(*[int(p) for p in peer_ptrs][:max(world, 1)]) if world else None
+        self._check(self._L.cfmm_set_peers(self._h, arr, int(world), int(rank), C.c_uint64(int(seq))))
 
     def sweep_dev(self, d_v_ptr: int, d_out_ptr: int, materialize: bool):
         self._check(self._L.cfmm_sweep_dev(self._h, C.c_void_p(d_v_ptr), C.c_void_p(d_out_ptr),

@@ -91,6 +91,11 @@ struct cfmm_ctx {
     int* d_tok_chunk_off = nullptr; // [n+1]
     double* d_chunk_sums = nullptr; // [n_chunks]
     int n_chunks = 0;
+    // sharded operation (cfmm_set_peers): every host-pointer sweep ends with the one-shot peer
+    // all-reduce of peer_allreduce.hip, so eval / find_arb / route return GLOBAL {Ψ, acc}
+    std::vector<uint64_t> peers;  // device addresses of all ranks' symmetric buffers
+    int peer_rank = 0;
+    uint64_t peer_seq = 0;
     double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out
     double* d_stage = nullptr;    // device address of h_stage
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
@@ -462,24 +467,30 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
     HIP_TRY(c, hipSetDevice(c->device));
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
     double* h_out = c->h_stage + c->n;
-    if (c->opt_zero_copy != 0 && !global_bins(c) && c->d_stage) {
-        // The row fold writes {Ψ, acc} straight into the pinned host staging buffer (mapped into
-        // the device's address space), and for small n every block also reads v from it: no copy
-        // commands on the stream, the PCIe round trip for v hides behind the first tile's pool
-        // loads.  Larger v (every block re-reads it) goes through one H2D copy instead.
-        const double* v_src = c->d_stage;
-        if (c->n > 1024) {
-            HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            v_src = c->d_v;
-        }
-        int rc = enqueue_sweep(c, v_src, c->d_stage + c->n, materialize);
-        if (rc != CFMM_OK) return rc;
-    } else {
+    const bool zero_copy = c->opt_zero_copy != 0 && c->d_stage != nullptr;
+    // v: small vectors are read by every block straight from the mapped pinned buffer (the PCIe
+    // round trip hides behind the first tile's pool loads); larger ones go through one H2D copy.
+    const double* v_src = c->d_stage;
+    if (!zero_copy || c->n > 1024 || global_bins(c)) {
         HIP_TRY(c, hipMemcpyAsync(c->d_v, c->h_stage, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        int rc = enqueue_sweep(c, c->d_v, c->d_out, materialize);
-        if (rc != CFMM_OK) return rc;
-        HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        v_src = c->d_v;
     }
+    // {Ψ, acc}: the last kernel of the evaluation writes into the mapped pinned buffer when it can
+    double* out_dst = zero_copy ? c->d_stage + c->n : c->d_out;
+    if (!c->peers.empty()) {
+        // sharded: fold into this rank's symmetric slot, then the one-shot gather over xGMI
+        const uint64_t seq = ++c->peer_seq;
+        double* slot = reinterpret_cast<double*>(c->peers[(size_t)c->peer_rank]) + (seq & 1ull) * (uint64_t)(c->n + 1);
+        int rc = enqueue_sweep(c, v_src, slot, materialize);
+        if (rc != CFMM_OK) return rc;
+        rc = cfmm_peer_allreduce(c->stream, c->peers.data(), (int32_t)c->peers.size(), c->peer_rank, c->n + 1, seq, out_dst);
+        if (rc != CFMM_OK) return fail(c, rc, "cfmm_peer_allreduce launch failed");
+    } else {
+        int rc = enqueue_sweep(c, v_src, out_dst, materialize);
+        if (rc != CFMM_OK) return rc;
+    }
+    if (!zero_copy)
+        HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (c->opt_spin_wait != 0) {
         // busy-poll the stream instead of a blocking wait: the evaluation is ~30 us long and the
         // caller (an L-BFGS-B step) has nothing else to do meanwhile
@@ -490,6 +501,8 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->last_out.assign(h_out, h_out + c->n + 1);
+    if (!c->peers.empty() && c->last_out[0] != c->last_out[0])
+        return fail(c, CFMM_ERR_STATE, "peer all-reduce timed out: a rank did not publish its {psi, acc}");
     c->have_out = true;
     return CFMM_OK;
 }
@@ -934,6 +947,22 @@ int cfmm_kernel_times(cfmm_ctx* c, int64_t* sweep_launches, double* sweep_ms, in
     if (reduce_ms) *reduce_ms = c->t_reduce_ms;
     c->t_sweep_n = c->t_reduce_n = 0;
     c->t_sweep_ms = c->t_reduce_ms = 0;
+    return CFMM_OK;
+}
+
+int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (world == 0) { // back to single-GPU operation
+        c->peers.clear();
+        return CFMM_OK;
+    }
+    if (!peer_buffers || world < 1 || world > 16 || rank < 0 || rank >= world)
+        return fail(c, CFMM_ERR_INVALID_ARG, "bad peer configuration");
+    if (global_bins(c)) return fail(c, CFMM_ERR_UNSUPPORTED, "sharded operation is limited to n_tokens <= %d", kMaxLdsTokens);
+    c->peers.assign(peer_buffers, peer_buffers + world);
+    c->peer_rank = rank;
+    c->peer_seq = seq;
     return CFMM_OK;
 }
 

@@ -196,5 +196,17 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
     if _local_backend_factory is not None:
         backend = _local_backend_factory(n_tokens, local)
     else:
-        backend = DeviceBackend(n_tokens, local, device=rank if device is None else device)
+        import torch
+        dev = rank if device is None else device
+        backend = DeviceBackend(n_tokens, local, device=dev)
+        if dist.get_backend(group) == "nccl" and n_tokens <= 8192:
+            # fast path: the all-reduce happens INSIDE the library at the end of every sweep
+            # (cfmm_set_peers), so find_arb_/route_ -- including the one-call native route! -- work on
+            # the global market unchanged.  Falls through to ShardedBackend (RCCL) if unavailable.
+            with torch.cuda.device(dev):
+                peer = PeerAllReduce.create(n_tokens + 1, group, torch.device("cuda", dev))
+            if peer is not None:
+                backend.ctx.set_peers([int(p) for p in peer.hdl.buffer_ptrs], world, rank, peer.seq)
+                backend.peer = peer   # keeps the symmetric allocation alive
+                return Router(objective, local, n_tokens, _backend=backend)
     return Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))

@@ -154,6 +154,14 @@ int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
 int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t world, int32_t rank,
                         int64_t count, uint64_t seq, double* d_out);
 
+/* Sharded operation of a context: after this call every host-pointer sweep (cfmm_find_arb,
+ * cfmm_eval, and therefore cfmm_route) ends with cfmm_peer_allreduce over the given symmetric
+ * buffers ([2][n_tokens+1] doubles + 2 uint64 flags each, see above), so psi / acc / route results
+ * are those of the WHOLE market while the context stores only this rank's shard.  Every rank must
+ * issue the same sequence of sweeps (route! does: all ranks take bit-identical L-BFGS-B steps).
+ * seq = number of all-reduces already performed on these buffers.  world = 0 switches it off. */
+int cfmm_set_peers(cfmm_ctx* ctx, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq);
+
 /* ---- route! without an interpreter in the loop ----------------------- */
 
 #define CFMM_OBJ_LINEAR_NONNEGATIVE 0 /* LinearNonnegative(c)      src/objectives.jl:51-79 */

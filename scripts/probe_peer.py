@@ -23,5 +23,10 @@ r = crd.ShardedRouter(obj, market, n, device=lr)
 cr.route_(r, v=np.ones(n))
 single = cr.Router(obj, market, n, device=lr)
 cr.route_(single, v=np.ones(n))
-print("sharded(1) vs single netflow diff:", float(np.max(np.abs(cr.netflows(r) - cr.netflows(single)))), "peer used:", r._backend._peer is not None)
+print("sharded(1) vs single netflow diff:", float(np.max(np.abs(cr.netflows(r) - cr.netflows(single)))),
+      "in-library peer path:", isinstance(r._backend, cr.DeviceBackend))
+r2 = crd.ShardedRouter(obj, market, n, device=lr)
+cr.route_(r2, v=np.ones(n), solver="native")
+cr.route_(single, v=np.ones(n), solver="native")
+print("native one-call sharded route vs single:", float(np.max(np.abs(cr.netflows(r2) - cr.netflows(single)))), r2.info)
 dist.destroy_process_group()
