@@ -240,29 +240,46 @@ def main():
     # sharded route!: every rank drives the same L-BFGS-B on the all-reduced {Ψ, acc} of its own shard
     route_sharded = None
     if use_dist:
-        from cfmmrouter_amd import dist as crd
-        obj = objective_for(args.workload, n)
-        v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
-        sr = crd.ShardedRouter(obj, batches, n, device=local_rank, already_sharded=True)
-        cr.route_(sr, v=v0, solver="native")
-        ts = []
-        for _ in range(3):
-            dist.barrier()
-            t0 = time.perf_counter()
-            cr.route_(sr, v=v0, solver="native")
-            ts.append(time.perf_counter() - t0)
-        tmax = torch.tensor([min(ts)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        vchk = torch.from_numpy(sr.v.copy()).to("cuda")
-        vmax, vmin = vchk.clone(), vchk.clone()
-        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
-        route_sharded = {"ms": 1e3 * float(tmax.item()), "evaluations": sr.info.get("funcalls"),
-                         "pools_total": world * m_rank, "ranks_agree_on_v": bool(torch.equal(vmax, vmin)),
-                         "max_netflow": float(np.max(np.abs(cr.netflows(sr)))),
-                         "collective": ("peer all-reduce inside the library (cfmm_set_peers), route! = one call per rank"
-                                        if isinstance(sr._backend, cr.DeviceBackend) else "rccl via torch.distributed")}
-        sr.close()
+        def all_ok(flag):   # collective vote, so that no rank walks into a collective alone
+            t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item()) == 1.0
+
+        sr, err = None, None
+        try:
+            from cfmmrouter_amd import dist as crd
+            obj = objective_for(args.workload, n)
+            v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
+            sr = crd.ShardedRouter(obj, batches, n, device=local_rank, already_sharded=True)
+            cr.route_(sr, v=v0, solver="native")   # warm
+        except Exception as e:
+            err = repr(e)[:300]
+        if all_ok(err is None):
+            ts = []
+            try:
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    cr.route_(sr, v=v0, solver="native")
+                    ts.append(time.perf_counter() - t0)
+            except Exception as e:
+                err = repr(e)[:300]
+            if all_ok(err is None):
+                tmax = torch.tensor([min(ts)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                vchk = torch.from_numpy(sr.v.copy()).to("cuda")
+                vmax, vmin = vchk.clone(), vchk.clone()
+                dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+                route_sharded = {"ms": 1e3 * float(tmax.item()), "evaluations": sr.info.get("funcalls"),
+                                 "pools_total": world * m_rank, "ranks_agree_on_v": bool(torch.equal(vmax, vmin)),
+                                 "max_netflow": float(np.max(np.abs(cr.netflows(sr)))),
+                                 "collective": ("peer all-reduce inside the library (cfmm_set_peers), route! = one call "
+                                                "per rank" if isinstance(sr._backend, cr.DeviceBackend)
+                                                else "rccl via torch.distributed")}
+        if route_sharded is None:
+            route_sharded = {"error": err or "another rank failed"}
+        if sr is not None:
+            sr.close()
 
     # the synchronous host-pointer boundary (what a ccall from Julia pays per evaluation):
     # pageable v in, Ψ/acc out over PCIe, one stream sync -- never the headline value
