@@ -558,3 +558,50 @@ def test_full_size_properties_config3_and_config5():
                              bu.lower_ticks.reshape(-1, 2)[i].reshape(-1), bu.liquidity.reshape(-1, 2)[i].reshape(-1), v)
     np.testing.assert_array_equal(D[i], Du)
     np.testing.assert_array_equal(L[i], Lu)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_markets_differential(seed):
+    """Random market shapes / families / token counts / launch options: device vs oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([2, 3, 17, 64, 300, 1500, 9000]))
+    segs = []
+    for _ in range(int(rng.integers(1, 6))):
+        kind = int(rng.integers(0, 4))
+        m = int(rng.choice([1, 63, 64, 65, 1000, 5000, 40_000]))
+        sd = int(rng.integers(1, 10_000))
+        if kind == 0:
+            segs.append(synth.product_pools(m, n, seed=sd))
+        elif kind == 1:
+            segs.append(synth.geomean_pools(m, n, seed=sd))
+        elif kind == 2:
+            segs.append(synth.bounded_product_pools(m, n, seed=sd))
+        else:
+            segs.append(synth.univ3_pools(min(m, 5000), n, int(rng.integers(1, 30)), seed=sd))
+    v = synth.sweep_prices(n, seed=seed, spread=float(rng.choice([0.01, 0.3, 2.0])))
+    opts = {}
+    if rng.random() < 0.5:
+        opts["fuse_segments"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        opts["block"] = int(rng.choice([256, 512, 1024]))
+    if rng.random() < 0.3:
+        opts["max_grid"] = int(rng.choice([1, 3, 64]))
+    if rng.random() < 0.3:
+        opts["bin_copies"] = int(rng.choice([1, 2]))
+    mat = bool(rng.random() < 0.7)
+    D, L, psi, acc = device_sweep(segs, n, v, materialize=mat, **opts)
+    Do, Lo, psio, acco = oracle_sweep(segs, n, v)
+    if mat:
+        off = 0
+        for b in segs:
+            sl = slice(off, off + len(b))
+            if b.kind == 1:      # geometric mean: log-space forms
+                scale = np.max(b.R, axis=1, keepdims=True)
+                assert np.max(np.abs(D[sl] - Do[sl]) / scale) <= GEOM_RTOL
+                assert np.max(np.abs(L[sl] - Lo[sl]) / scale) <= GEOM_RTOL
+            else:                # product / univ3: bit-exact
+                np.testing.assert_array_equal(D[sl], Do[sl])
+                np.testing.assert_array_equal(L[sl], Lo[sl])
+            off += len(b)
+    assert rel_to_max(psi, psio) <= 1e-10
+    assert abs(acc - acco) <= 1e-9 * max(abs(acco), 1.0)
