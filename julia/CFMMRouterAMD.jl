@@ -17,7 +17,7 @@ using CFMMRouter: CFMM, ProductTwoCoin, GeometricMeanTwoCoin, UniV3, Objective
 using LBFGSB
 import CFMMRouter: route!, netflows, netflows!, find_arb!
 
-export AMDRouter
+export AMDRouter, route_native!
 
 const LIB = get(ENV, "CFMM_AMD_LIB", "libcfmm_amd.so")
 
@@ -154,6 +154,46 @@ function route!(r::AMDRouter; v=nothing, verbose=false, m=5, factr=1e1, pgtol=1e
                         maxfun=maxfun, maxiter=maxiter)
     r.v .= vopt
     find_arb!(r, vopt)                                          # src/router.jl:107
+end
+
+# Optional fast path: the whole of route! inside the library (cfmm_route: its own L-BFGS-B, the
+# objective's f/grad!/bounds restated in C++) -- one ccall, no Julia between two device sweeps.
+struct RouteInfo
+    f::Float64
+    proj_grad::Float64
+    iterations::Int32
+    evaluations::Int32
+    sweeps::Int32
+    status::Int32
+end
+
+function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000)
+    obj = r.objective
+    kind, vec, idx = if obj isa CFMMRouter.LinearNonnegative
+        (Int32(0), Vector{Float64}(obj.c), Int32(0))
+    elseif obj isa CFMMRouter.BasketLiquidation
+        (Int32(1), Vector{Float64}(obj.Δin), Int32(obj.i - 1))
+    else
+        throw(ArgumentError("route_native! knows LinearNonnegative and BasketLiquidation"))
+    end
+    n = length(r.v)
+    vout = Vector{Float64}(undef, n)
+    info = Ref(RouteInfo(0.0, 0.0, 0, 0, 0, 0))
+    v0vec = isnothing(v) ? Float64[] : Vector{Float64}(v)
+    GC.@preserve vec v0vec vout check(r.ctx, ccall((:cfmm_route, LIB), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Float64, Float64, Int32, Int32,
+         Ptr{Float64}, Ptr{Float64}, Ref{RouteInfo}),
+        r.ctx, kind, vec, idx, isnothing(v) ? C_NULL : pointer(v0vec), m, factr, pgtol, maxfun, maxiter,
+        vout, r.Ψ, info))
+    r.v .= vout
+    # trades were materialised at v* by the same call
+    mm = length(r.cfmms)
+    D = Matrix{Float64}(undef, 2, mm); L = Matrix{Float64}(undef, 2, mm)
+    GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
+    for (k, i) in enumerate(r.order)
+        r.Δs[i] .= @view D[:, k]; r.Λs[i] .= @view L[:, k]
+    end
+    return info[]
 end
 
 # netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125
