@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and route legs")
     ap.add_argument("--fused", action="store_true", help="time the fused evaluation (no Δ/Λ write-back)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cache-cold pass")
     ap.add_argument("--rccl", action="store_true", help="force the RCCL all-reduce instead of the one-shot peer gather")
     args = ap.parse_args()
 
@@ -225,6 +226,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # cold pass: every working set here (<= 100 MB) fits the 256 MB Infinity Cache, so
+    # the passes above are "warm" (what a running route! sees).  Rotating over enough distinct copies
+    # of the market to exceed 300 MB makes every sweep read its pool state from HBM.
+    cold = None
+    if world == 1 and not use_dist and not args.no_cold:
+        per_copy = alg_bytes(batches, True) + 16 * sum(len(b) for b in batches if b.kind == KIND_GEOMEAN)
+        copies = int(np.ceil(320e6 / per_copy)) + 1
+        extra = [cr.DeviceBackend(n, batches, device=local_rank) for _ in range(copies - 1)]
+        ring = [be] + extra
+        outs = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in ring]
+        for b_ in ring:
+            b_.ctx.set_stream(stream.cuda_stream)
+        for k in range(2 * copies):
+            ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), outs[k % copies].data_ptr(), materialize)
+        torch.cuda.synchronize()
+        for b_ in ring:
+            b_.ctx.set_option("time_kernels", 1)
+            b_.ctx.kernel_times()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), outs[k % copies].data_ptr(), materialize)
+        torch.cuda.synchronize()
+        cold_elapsed = time.perf_counter() - t0
+        sw = sum(b_.ctx.kernel_times()["sweep_ms"] for b_ in ring) / args.steps
+        for b_ in ring:
+            b_.ctx.set_option("time_kernels", 0)
+        cold = {"copies": copies, "bytes_rotated": copies * per_copy, "kernel_ms": sw,
+                "achieved": alg_bytes(batches, materialize) / (sw * 1e-3) / 1e9 if sw > 0 else 0.0,
+                "ms_per_step_with_kernel_events": 1e3 * cold_elapsed / args.steps}
+        cold["frac"] = cold["achieved"] / HBM_PEAK_GBS
+        for b_ in extra:
+            b_.close()
+        be.ctx.set_stream(stream.cuda_stream)
 
     # sharded runs: the timed path's global {Ψ, acc} against a plain RCCL all-reduce of the local ones
     collective_check = None
@@ -345,6 +380,9 @@ def main():
                      "kernel": "cfmm::sweep_kernel (all segment launches of one step)",
                      "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": sweep_ms,
                      "reduce_kernel_ms": kt["reduce_ms"] / max(args.steps, 1),
+                     "residency": "warm: the same market is swept every step and fits the 256 MB Infinity Cache "
+                                  "(as inside route!); see `cold` for HBM-resident pool state",
+                     "cold": cold,
                      "step_ms_device_events": dev_ms / args.steps,
                      "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
                      "how": "kernel_ms = mean hipEvent-bracketed duration of the sweep launches over a "
