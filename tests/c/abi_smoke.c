@@ -28,14 +28,14 @@ int main(void)
     const int32_t Ai[4] = {0, 1, 0, 1};
     CHECK(cfmm_pools_add_product(ctx, 2, R, gamma, Ai));
 
-    /* find_arb!(r, v) at v = [2, 1] and the trades of pool 2 */
+    /* find_arb!(r, v) at v = [2, 1] and the trades of pool 1 (pool 2 sits exactly at that price) */
     const double v[2] = {2.0, 1.0};
     double D[4], L[4], psi[2], acc;
     CHECK(cfmm_find_arb(ctx, v));
     CHECK(cfmm_get_trades(ctx, D, L));
     CHECK(cfmm_netflows(ctx, psi));
     CHECK(cfmm_dual_value(ctx, &acc));
-    printf("trades pool2: D=[%.17g, %.17g] L=[%.17g, %.17g]\n", D[2], D[3], L[2], L[3]);
+    printf("trades pool1: D=[%.17g, %.17g] L=[%.17g, %.17g]\n", D[0], D[1], L[0], L[1]);
     printf("netflows at v=[2,1]: [%.17g, %.17g] acc=%.17g\n", psi[0], psi[1], acc);
 
     /* the same evaluation without trade write-back */

@@ -19,11 +19,14 @@ def test_plain_c_client(tmp_path):
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
     print(out)
-    D, L = orc.product_find_arb([1e3, 2e3], 1.0, [2.0, 1.0])
-    line = [l for l in out.splitlines() if l.startswith("trades pool2")][0]
-    nums = [float(x) for x in line.replace("[", " ").replace("]", " ").replace(",", " ").split() if x[0].isdigit() or x[0] == "-"]
+    D, L = orc.product_find_arb([1e6, 1e6], 1.0, [2.0, 1.0])
+    assert D[1] > 0 and L[0] > 0
+    line = [l for l in out.splitlines() if l.startswith("trades pool1")][0]
+    nums = [float(x) for x in line.split(":", 1)[1].replace("D=", " ").replace("L=", " ").replace("[", " ")
+            .replace("]", " ").replace(",", " ").split()]
     assert nums == [D[0], D[1], L[0], L[1]]          # %.17g round-trips binary64: bit-exact through the C client
-    assert "route: v=[1.000828" in out and "two token indices must differ" in out
+    assert "route: v=[1.0008" in out and "psi=[-2.5" in out and "171.40" in out
+    assert "two token indices must differ" in out
 
 
 def test_plain_c_client_compiles():
