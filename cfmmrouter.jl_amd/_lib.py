@@ -112,7 +112,7 @@ def lib():
     L.cfmm_route.argtypes = [_ctx, C.c_int32, _f64p, C.c_int32, _f64p, C.c_int32, C.c_double, C.c_double,
                              C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(RouteInfo)]
     L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
-                                       C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
+                                       C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
     L.cfmm_set_peers.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64]
     L.cfmm_peer_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_uint64, C.c_void_p]
@@ -316,15 +316,20 @@ class Context:
         return out
 
 
-def lbfgsb_minimize(fun, x0, bounds, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000):
+def lbfgsb_minimize(fun, x0, bounds, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000,
+                    reference_boxed=False):
     """The library's own L-BFGS-B on a Python objective `fun(x) -> (f, g)` (host only; used by the
-    CPU tests to compare the solver with SciPy's).  bounds: list of (lo, hi) with None = unbounded."""
+    CPU tests to compare the solver with SciPy's).  bounds: list of (lo, hi) with None = unbounded.
+    reference_boxed=True passes nbd = 2 for every variable (infinite bounds included) and lets the
+    solver take the Fortran code's "boxed" first step, as the reference's call does."""
     n = len(x0)
     x = f64(np.array(x0, dtype=np.float64).copy())
     lo = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
     hi = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
     nbd = np.array([(1 if np.isfinite(l) else 0) + (2 if np.isfinite(h) else 0) for l, h in zip(lo, hi)])
     nbd = np.array([{0: 0, 1: 1, 3: 2, 2: 3}[int(k)] for k in nbd], dtype=np.int32)
+    if reference_boxed:
+        nbd[:] = 2
 
     def cb(_user, xp, gp):
         xx = np.ctypeslib.as_array(xp, shape=(n,))
@@ -334,7 +339,8 @@ def lbfgsb_minimize(fun, x0, bounds, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, 
 
     info = RouteInfo()
     rc = lib().cfmm_lbfgsb_minimize(n, ptr(x), ptr(lo), ptr(hi), ptr(nbd), FG_CALLBACK(cb), None, int(m),
-                                    float(factr), float(pgtol), int(maxfun), int(maxiter), C.byref(info))
+                                    float(factr), float(pgtol), int(maxfun), int(maxiter),
+                                    1 if reference_boxed else 0, C.byref(info))
     if rc != OK:
         raise ArgumentError(lib().cfmm_last_error(None).decode())
     return x, info.as_dict()

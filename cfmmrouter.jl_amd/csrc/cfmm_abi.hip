@@ -968,10 +968,11 @@ int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int
 
 int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
                          cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
-                         int32_t maxiter, cfmm_route_info* info)
+                         int32_t maxiter, int32_t boxed_from_nbd, cfmm_route_info* info)
 {
     if (n < 1 || !x || !nbd || !fg) return fail(nullptr, CFMM_ERR_INVALID_ARG, "bad argument to cfmm_lbfgsb_minimize");
     LbfgsbOptions opt;
+    opt.boxed_from_nbd = boxed_from_nbd != 0;
     opt.m = m;
     opt.factr = factr;
     opt.pgtol = pgtol;
@@ -1061,6 +1062,7 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     opt.pgtol = pgtol;
     opt.maxfun = maxfun;
     opt.maxiter = maxiter;
+    opt.boxed_from_nbd = true; // bounds[1,:] .= 2 with an infinite upper limit: the Fortran's "boxed" path
     LbfgsbResult r = lbfgsb_minimize(n, v.data(), lo.data(), up.data(), nbd.data(), fg, opt); // :105
     if (rc_inner != CFMM_OK) return rc_inner;
     int rc = host_sweep(c, v.data(), true); // src/router.jl:106-107: r.v = v*, find_arb!(r, v*)

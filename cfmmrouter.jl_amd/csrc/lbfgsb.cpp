@@ -286,8 +286,9 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
     const int m = std::max(1, opt.m);
     std::vector<int> nbd(nbd_in, nbd_in + n);
     std::vector<double> l(n), u(n);
-    bool constrained = false, boxed = true;
+    bool constrained = false, boxed = true, boxed_as_given = true;
     for (int i = 0; i < n; ++i) {
+        if (nbd_in[i] != 2) boxed_as_given = false;
         l[i] = lower ? lower[i] : -kInf;
         u[i] = upper ? upper[i] : kInf;
         // infinite bounds are no bounds (the reference passes nbd = 2 with u = Inf, src/router.jl:68-70)
@@ -300,6 +301,8 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         if (hl && x[i] < l[i]) x[i] = l[i];
         if (hu && x[i] > u[i]) x[i] = u[i];
     }
+
+    if (opt.boxed_from_nbd) boxed = boxed_as_given;
 
     Memory mem;
     mem.n = n;

@@ -28,6 +28,11 @@ struct LbfgsbOptions {
     int maxfun = 15000;
     int maxiter = 15000;
     int max_linesearch = 20;
+    // The Fortran code calls a problem "boxed" when every nbd[i] == 2, whatever the bound VALUES
+    // are, and then takes a unit first step instead of min(1/|d|, stpmx).  The reference passes
+    // nbd = 2 with an infinite upper bound (src/router.jl:67-70), i.e. it runs boxed; SciPy maps
+    // an infinite bound to "no bound" and therefore does not.  true = the reference's behaviour.
+    bool boxed_from_nbd = false;
 };
 
 struct LbfgsbResult {

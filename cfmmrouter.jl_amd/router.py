@@ -262,7 +262,8 @@ def _route_native(r: Router, v, m, factr, pgtol, maxfun, maxiter):
         return _obj.f(r.objective, x) + r._acc, G + r._psi
 
     sweep(r.v)
-    x, info = lbfgsb_minimize(fg, r.v.copy(), bounds, m=m, factr=factr, pgtol=pgtol, maxfun=maxfun, maxiter=maxiter)
+    x, info = lbfgsb_minimize(fg, r.v.copy(), bounds, m=m, factr=factr, pgtol=pgtol, maxfun=maxfun, maxiter=maxiter,
+                              reference_boxed=True)   # nbd = 2 with u = Inf, as src/router.jl:67-70
     r.v[:] = x
     r.info = {"f": info["f"], "funcalls": info["evaluations"], "nit": info["iterations"],
               "warnflag": 0 if info["status"] in (0, 1) else 2, "task": info["status"], "solver": "native"}

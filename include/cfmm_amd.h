@@ -188,11 +188,14 @@ int cfmm_route(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_ve
                double* v_out, double* psi_out, cfmm_route_info* info);
 
 /* The solver alone on a caller-supplied objective (used by the CPU tests to compare it with
- * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g. */
+ * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g.
+ * boxed_from_nbd != 0: like the Fortran code, treat the problem as "boxed" (unit first step) when
+ * every nbd[i] == 2 even if a bound is infinite -- what the reference's call does
+ * (src/router.jl:67-70) and what cfmm_route uses; 0: infinite bounds are no bounds (SciPy). */
 typedef double (*cfmm_fg_callback)(void* user, const double* x, double* g);
 int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
                          cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
-                         int32_t maxiter, cfmm_route_info* info);
+                         int32_t maxiter, int32_t boxed_from_nbd, cfmm_route_info* info);
 
 /* Number of segments and their description (kind, pool count, launch geometry). */
 int32_t cfmm_segment_count(const cfmm_ctx* ctx);

@@ -85,6 +85,11 @@ def test_dual_problem_matches_scipy(m, n, kind):
         return oo.f(v) + orc.dual_acc(D, L, ps.Ai, v), G
 
     lo = oo.lower_limit()
+    # the reference's own call shape (nbd = 2 everywhere, u = Inf -> the Fortran's "boxed" first step)
+    vb, infob = lbfgsb_minimize(fg, v0, [(lo[j], None) for j in range(n)], reference_boxed=True)
+    Db, Lb = ps.sweep(vb)
+    assert rel_to_max(orc.netflows(Db, Lb, ps.Ai, n), ref["psi"]) <= 1e-6
+    assert abs(infob["f"] - ref["f"]) <= 1e-9 * max(1.0, abs(ref["f"]))
     v, info = lbfgsb_minimize(fg, v0, [(lo[j], None) for j in range(n)])
     assert info["status"] in (0, 1), info
     D, L = ps.sweep(v)
