@@ -53,8 +53,8 @@ class PeerAllReduce:
         self._ptrs = (C.c_uint64 * self.world)(*ptrs)
         self.seq = 0
         torch.cuda.synchronize(device)
-        self.hdl.barrier()                               # everybody's flags are zero before step 1
-        torch.cuda.synchronize(device)
+        dist.barrier(group=group)                        # everybody's flags are zero before step 1 (plain RCCL
+        torch.cuda.synchronize(device)                   # barrier: nothing here may spin on a peer mapping)
 
     def slot(self):
         """Device view [count] that the NEXT reduce() will read as this rank's contribution."""
