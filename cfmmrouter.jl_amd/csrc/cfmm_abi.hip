@@ -34,7 +34,7 @@ struct Segment {
     // device arrays (owned)
     double2* R = nullptr;
     double2* w = nullptr;
-    double2* ew = nullptr;   // geomean: {η, 1/(η+1)}
+    double* eta = nullptr;   // geomean: η = w1/w2
     double2* lR = nullptr;   // geomean: {log R1, log R2}
     double* gamma = nullptr;
     int2* Ai = nullptr;
@@ -161,7 +161,7 @@ int upload(cfmm_ctx* c, T** dst, const void* src, size_t count)
 void free_segment(Segment& s)
 {
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
-    (void)hipFree(s.ew); (void)hipFree(s.lR);
+    (void)hipFree(s.eta); (void)hipFree(s.lR);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
     (void)hipFree(s.pg); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
     s = Segment{};
@@ -404,7 +404,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.gflow = gb ? c->d_flow + s.trade_off : nullptr;
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
-                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}; break;
+                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact}; break;
                 default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
                 }
             }
@@ -419,7 +419,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN:
-                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.ew, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
+                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
                 break;
             default:
                 e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}, a, cfg, materialize, c->stream);
@@ -685,17 +685,17 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
         if (!finite_pos(w[2 * i]) || !finite_pos(w[2 * i + 1]))
             return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: weights must be finite and > 0", (long long)i);
     // v-independent pieces of the log-space closed forms (sweep_kernels.hip, GeoMeanLogOps)
-    std::vector<double2> ew((size_t)m), lR((size_t)m);
+    std::vector<double2> lR((size_t)m);
+    std::vector<double> etas((size_t)m);
     for (int64_t i = 0; i < m; ++i) {
-        const double eta = w[2 * i] / w[2 * i + 1]; // src/cfmms.jl:188
-        ew[(size_t)i] = make_double2(eta, 1.0 / (eta + 1.0));
+        etas[(size_t)i] = w[2 * i] / w[2 * i + 1]; // src/cfmms.jl:188
         lR[(size_t)i] = make_double2(std::log(R[2 * i]), std::log(R[2 * i + 1]));
     }
     HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
     s.kind = CFMM_KIND_GEOMEAN;
     s.m = m;
-    if ((rc = upload(c, &s.ew, ew.data(), (size_t)m)) || (rc = upload(c, &s.lR, lR.data(), (size_t)m)) ||
+    if ((rc = upload(c, &s.eta, etas.data(), (size_t)m)) || (rc = upload(c, &s.lR, lR.data(), (size_t)m)) ||
         (rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.w, w, (size_t)m)) ||
         (rc = upload(c, &s.gamma, gamma, (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
         free_segment(s);

@@ -28,7 +28,7 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* w;            // [m] {w1, w2}
     const double* gamma;
     const int2* Ai;
-    const double2* ew;           // [m] {η = w1/w2, 1/(η+1)}      prepared at upload
+    const double* eta;           // [m] η = w1/w2                  prepared at upload
     const double2* lR;           // [m] {log R1, log R2}          prepared at upload
     int reference_order;         // 1: evaluate with pow in the reference's operation order
 };

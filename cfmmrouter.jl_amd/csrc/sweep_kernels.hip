@@ -159,8 +159,8 @@ struct GeoMeanOps {
 // With c = γ·m·e·r_a (the pow-free factor of :180), l_x = log x:
 //     (c·r_b^e)^(1/(e+1))                    = exp((l_c + e·l_b) / (e+1))
 //     ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = exp((l_a + e·(l_b − l_c + l_a)) / (1+e))
-// Everything that does not depend on v is prepared once at upload (cfmm_abi.hip): η = w₁/w₂,
-// 1/(η+1), log R₁, log R₂.  Direction 2 uses e = 1/η, for which the two exponents become
+// Everything that does not depend on v and is worth its bytes is prepared once at upload
+// (cfmm_abi.hip): η = w₁/w₂, log R₁, log R₂ (1/(η+1) is recomputed: a division is cheaper than 8 B).  Direction 2 uses e = 1/η, for which the two exponents become
 // (η·l_c + l_b)/(η+1) and (η·l_a + (l_b − l_c) + l_a)/(η+1) -- no further division.  Per trading
 // pool that leaves 1 log + 2 exp + 2 divisions (c and the final /γ) instead of 4 pow + 6
 // divisions; pools inside the no-arbitrage band cost two multiplies and a compare.
@@ -170,20 +170,20 @@ struct GeoMeanOps {
 struct GeoMeanLogOps {
     static constexpr bool kWaveCooperative = false;
     struct Raw {
-        double2 R, ew, lR;
-        double g;
+        double2 R, lR;
+        double eta, g;
         int2 ai;
     };
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        return Raw{p.R[i], p.ew[i], p.lR[i], p.gamma[i], p.Ai[i]};
+        return Raw{p.R[i], p.lR[i], p.eta[i], p.gamma[i], p.Ai[i]};
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
     {
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
-        const double eta = r.ew.x, inv = r.ew.y;      // η, 1/(η+1)
+        const double eta = r.eta;                     // η = w₁/w₂, prepared at upload
         const double n1 = ((g * v2) * eta) * R2, d1 = v1;   // c₁ = n1/d1: direction 1 trades iff c₁ > R₁
         const double n2 = (g * v1) * R1, d2 = v2 * eta;     // c₂ = n2/d2: direction 2 trades iff c₂ > R₂
         const bool p1 = n1 > R1 * d1, p2 = n2 > R2 * d2;
@@ -201,6 +201,7 @@ struct GeoMeanLogOps {
             const double u = (lb - lc) + la;
             const double A = dir1 ? (lc + eta * lb) : (eta * lc + lb);
             const double B = dir1 ? (la + eta * u) : (eta * la + u);
+            const double inv = 1.0 / (eta + 1.0);
             const double d = max0(exp(A * inv) - rb) / g;
             const double l = max0(ra - exp(B * inv));
             if (dir1) { t.d1 = d; t.l2 = l; }
