@@ -605,3 +605,21 @@ def test_randomized_markets_differential(seed):
             off += len(b)
     assert rel_to_max(psi, psio) <= 1e-10
     assert abs(acc - acco) <= 1e-9 * max(abs(acco), 1.0)
+
+
+def test_context_lifecycle_stress():
+    """create / upload / sweep / destroy many contexts: no leak-induced failure, results stay identical."""
+    b = synth.product_pools(2000, 8, seed=1)
+    v = synth.sweep_prices(8, seed=1)
+    first = None
+    for k in range(300):
+        be = cr.DeviceBackend(8, [b])
+        psi, acc = be.eval(v) if k % 2 else be.find_arb(v)
+        be.ctx.clear()
+        be.ctx.add_product(b.R, b.γ, (b.Ai - 1).astype(np.int32))      # pools can be replaced in place
+        psi2, _ = be.eval(v)
+        be.close()
+        np.testing.assert_array_equal(psi, psi2)
+        if first is None:
+            first = psi
+        np.testing.assert_array_equal(psi, first)
