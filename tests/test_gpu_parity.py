@@ -623,3 +623,38 @@ def test_context_lifecycle_stress():
         if first is None:
             first = psi
         np.testing.assert_array_equal(psi, first)
+
+
+def test_eight_shards_summed_equal_the_unsharded_sweep():
+    """shard-correctness on one GPU -- config 4's layout in miniature (contiguous blocks
+    of every family per rank): the 8 shards' {Ψ, acc}, summed in rank order, equal the whole market's."""
+    from cfmmrouter_amd.dist import shard_batches, shard_range
+    n = 512
+    market = [synth.product_pools(400_003, n, seed=4), synth.geomean_pools(50_001, n, seed=5),
+              synth.univ3_pools(20_005, n, 4, seed=6)]
+    v = synth.sweep_prices(n, seed=4)
+    be = cr.DeviceBackend(n, market)
+    psi_all, acc_all = be.find_arb(v)
+    D_all, L_all = be.trades()
+    be.close()
+    psi_sum, acc_sum, rows = np.zeros(n), 0.0, 0
+    for rank in range(8):
+        shard = shard_batches(market, rank, 8)
+        be = cr.DeviceBackend(n, shard)
+        psi, acc = be.find_arb(v)
+        D, L = be.trades()
+        be.close()
+        psi_sum += psi
+        acc_sum += acc
+        off_all = 0
+        off = 0
+        for b, full in zip(shard, market):          # every shard row is the unsharded row, bit for bit
+            lo, hi = shard_range(len(full), rank, 8)
+            np.testing.assert_array_equal(D[off:off + len(b)], D_all[off_all + lo:off_all + hi])
+            np.testing.assert_array_equal(L[off:off + len(b)], L_all[off_all + lo:off_all + hi])
+            off += len(b)
+            off_all += len(full)
+        rows += off
+    assert rows == sum(len(b) for b in market)
+    assert rel_to_max(psi_sum, psi_all) <= 1e-12
+    assert abs(acc_sum - acc_all) <= 1e-11 * abs(acc_all)
