@@ -6,6 +6,7 @@ sides, same operation order), GeometricMeanTwoCoin within a few ulp (different p
 implementations), reductions within 1e-12 of max|Ψ| (different summation order).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -560,7 +561,7 @@ def test_full_size_properties_config3_and_config5():
     np.testing.assert_array_equal(L[i], Lu)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CFMM_FUZZ_SEEDS", "12"))))
 def test_randomized_markets_differential(seed):
     """Random market shapes / families / token counts / launch options: device vs oracle."""
     rng = np.random.default_rng(1000 + seed)
