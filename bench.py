@@ -217,9 +217,9 @@ def main():
 
     # pass 1 -- THE timed region: K steps between barrier+synchronize, nothing else on the stream
     elapsed, dev_ms = timed_pass()
-    # pass 2 -- the same K steps again with a hipEvent pair around every kernel launch (on the
-    # launch stream) for the roofline; kept out of pass 1 because every event record is a barrier
-    # packet that opens a bubble between the ~10 us kernels
+    # pass 2 -- the same K steps again with a hipEvent pair attached to every kernel launch (start /
+    # stop written by the command processor, hipExtLaunchKernel) for the roofline; kept out of pass 1
+    # so that the timed region carries nothing but the work
     be.ctx.set_option("time_kernels", 1)
     be.ctx.kernel_times()  # reset
     elapsed2, _ = timed_pass()
@@ -388,9 +388,9 @@ def main():
                      "cold": cold,
                      "step_ms_device_events": dev_ms / args.steps,
                      "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
-                     "how": "kernel_ms = mean hipEvent-bracketed duration of the sweep launches over a "
-                            "second K-step pass; the bracket adds ~2.5 us to each ~10 us kernel vs rocprofv3 "
-                            "(profiles/), so frac is a lower bound"},
+                     "how": "kernel_ms = mean duration of the sweep launches over a second K-step pass, from "
+                            "hipEvent pairs written by the command processor at each kernel's start and stop "
+                            "(hipExtLaunchKernel) on the launch stream; compare profiles/*_kernel_stats.csv"},
     }
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check

@@ -382,10 +382,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.nt_stores = (int)c->opt_nt_stores;
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
-        if (timed) {
+        if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
             ea = take_event(c);
             eb = take_event(c);
-            if (ea && eb) HIP_TRY(c, hipEventRecord(ea, c->stream));
+            if (!ea || !eb) ea = eb = nullptr;
         }
         hipError_t e = hipSuccess;
         if (g.multi) {
@@ -408,14 +408,15 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
                 }
             }
-            e = launch_multi(ma, g.block, g.grid, lds, materialize, c->stream);
+            LaunchCfg cfg{g.block, g.grid, 1, lds, ea, eb};
+            e = launch_multi(ma, cfg, materialize, c->stream);
         } else {
             const Segment& s = c->segs[(size_t)g.first];
             a.m = s.m;
             a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
-            LaunchCfg cfg{g.block, g.grid, s.unroll, lds};
+            LaunchCfg cfg{g.block, g.grid, s.unroll, lds, ea, eb};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN:
@@ -427,16 +428,14 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             }
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "sweep launch failed: %s", hipGetErrorString(e));
-        if (timed && ea && eb) {
-            HIP_TRY(c, hipEventRecord(eb, c->stream));
-            c->pending.push_back({ea, eb, 0});
-        }
+        if (ea && eb) c->pending.push_back({ea, eb, 0});
     }
     hipEvent_t ra = nullptr, rb = nullptr;
     if (timed) {
         ra = take_event(c);
         rb = take_event(c);
-        if (ra && rb) HIP_TRY(c, hipEventRecord(ra, c->stream));
+        if (!ra || !rb) ra = rb = nullptr;
+        if (ra && (gb || c->rows_total == 0)) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
     }
     if (c->rows_total > 0) {
         hipError_t e;
@@ -444,14 +443,14 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
                               c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->d_partials, (int)c->rows_total, c->stream);
         } else {
-            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream);
+            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, ra, rb);
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
     }
-    if (timed && ra && rb) {
-        HIP_TRY(c, hipEventRecord(rb, c->stream));
+    if (ra && rb) {
+        if (gb || c->rows_total == 0) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
     if (materialize) c->have_trades = true;

@@ -85,6 +85,8 @@ struct LaunchCfg {
     int grid;
     int unroll;                  // 1, 2 or 4 pools per lane per tile
     size_t lds_bytes;
+    hipEvent_t ev_start = nullptr; // both set: the launch is timed by the command processor
+    hipEvent_t ev_stop = nullptr;  // (hipExtLaunchKernel), i.e. the kernel's own execution span
 };
 
 hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
@@ -95,8 +97,7 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
                         hipStream_t s);
 
 // grid must be a multiple of ma.nseg: block b sweeps segment b % nseg and writes partial row b.
-hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool materialize,
-                        hipStream_t s);
+hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool materialize, hipStream_t s);
 
 // Large markets: chunk_sums[c] = sum of flow[entries[chunks[c].x .. chunks[c].y)], then
 // out[t] = sum of chunk_sums[tok_chunk_off[t] .. tok_chunk_off[t+1]) for t < n and
@@ -105,7 +106,8 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
                          const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s);
 
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s);
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 size_t sweep_lds_bytes(int n_pad, int copies, int block);
 hipError_t prepare_kernels(size_t max_lds_bytes);

@@ -31,6 +31,8 @@
 
 #include "sweep.h"
 
+#include <hip/hip_ext.h>
+
 namespace cfmm {
 
 struct Trade {
@@ -681,6 +683,17 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// Plain launch, or -- when a start/stop event pair is given -- a launch whose events are written by
+// the command processor at the kernel's first and last wavefront (hipExtLaunchKernel): that is the
+// kernel's own execution span, the quantity rocprofv3 reports, without the ~2.5 us that a
+// hipEventRecord / launch / hipEventRecord bracket adds.
+template <class K, class... A>
+static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, A... args)
+{
+    if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, (std::uint32_t)lds, s, e0, e1, 0u, args...);
+    else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
+}
+
 size_t sweep_lds_bytes(int n_pad, int copies, int block)
 {
     return ((size_t)n_pad * (1 + copies) + block / 64) * sizeof(double);
@@ -704,23 +717,23 @@ static hipError_t set_lds_attr(size_t bytes)
 }
 
 template <int B>
-static void launch_multi_b(const MultiArgs& ma, int grid, size_t lds_bytes, bool mat, hipStream_t s)
+static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(grid), b(B);
+    dim3 g(c.grid), b(B);
     if (ma.common.gflow) {
-        if (mat) hipLaunchKernelGGL((sweep_multi<true, B, true>), g, b, lds_bytes, s, ma);
-        else hipLaunchKernelGGL((sweep_multi<false, B, true>), g, b, lds_bytes, s, ma);
+        if (mat) launch_k(&sweep_multi<true, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        else launch_k(&sweep_multi<false, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
     } else {
-        if (mat) hipLaunchKernelGGL((sweep_multi<true, B, false>), g, b, lds_bytes, s, ma);
-        else hipLaunchKernelGGL((sweep_multi<false, B, false>), g, b, lds_bytes, s, ma);
+        if (mat) launch_k(&sweep_multi<true, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        else launch_k(&sweep_multi<false, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
     }
 }
 
-hipError_t launch_multi(const MultiArgs& ma, int block, int grid, size_t lds_bytes, bool mat, hipStream_t s)
+hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (block == kBigBlock) launch_multi_b<kBigBlock>(ma, grid, lds_bytes, mat, s);
-    else if (block == kMidBlock) launch_multi_b<kMidBlock>(ma, grid, lds_bytes, mat, s);
-    else launch_multi_b<kSmallBlock>(ma, grid, lds_bytes, mat, s);
+    if (c.block == kBigBlock) launch_multi_b<kBigBlock>(ma, c, mat, s);
+    else if (c.block == kMidBlock) launch_multi_b<kMidBlock>(ma, c, mat, s);
+    else launch_multi_b<kSmallBlock>(ma, c, mat, s);
     return hipGetLastError();
 }
 
@@ -749,12 +762,13 @@ template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid), b(B);
+    hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
     if (a.gflow) { // large-market mode, one pool per lane per tile only
-        if (mat) hipLaunchKernelGGL((sweep_kernel<Ops, true, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
-        else hipLaunchKernelGGL((sweep_kernel<Ops, false, 1, B, true>), g, b, c.lds_bytes, s, ops, a);
+        if (mat) launch_k(&sweep_kernel<Ops, true, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);
         return;
     }
-#define CFMM_GO(MAT, U) hipLaunchKernelGGL((sweep_kernel<Ops, MAT, U, B>), g, b, c.lds_bytes, s, ops, a)
+#define CFMM_GO(MAT, U) launch_k(&sweep_kernel<Ops, MAT, U, B, false>, g, b, c.lds_bytes, s, e0, e1, ops, a)
     if (mat) {
         if (c.unroll == 4) CFMM_GO(true, 4);
         else if (c.unroll == 2) CFMM_GO(true, 2);
@@ -794,10 +808,11 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
     return launch_any(ops, a, c, mat, s);
 }
 
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s)
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, hipEvent_t e0,
+                         hipEvent_t e1)
 {
     dim3 g((n1 + kReduceCols - 1) / kReduceCols), b(kReduceBlock);
-    hipLaunchKernelGGL(reduce_partials, g, b, 0, s, partials, rows, n1, out);
+    launch_k(&reduce_partials, g, b, 0, s, e0, e1, partials, rows, n1, out);
     return hipGetLastError();
 }
 

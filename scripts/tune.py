@@ -40,7 +40,7 @@ def run(mat, steps=30, **opts):
     return 1e3 * kt["sweep_ms"] / steps, 1e3 * kt["reduce_ms"] / steps, be.ctx.segments()[0]
 
 
-print(f"# {what} m={m} n={n}  (event-timed: ~2.5 us above rocprof's kernel duration)")
+print(f"# {what} m={m} n={n}  (hipExtLaunchKernel start/stop events)")
 print("block unroll max_grid copies nt | sweep_us(mat) sweep_us(fused) reduce_us grid")
 for block, unroll, mg, cp, nt in itertools.product([256, 512, 1024], [1, 2, 4], [256, 512, 1024, 2048], [1, 2], [0, 1]):
     if block >= 512 and mg > 1024:
