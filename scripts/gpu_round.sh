@@ -12,7 +12,7 @@ fi
 if [ -n "$PROF" ]; then
   cd /tmp && export TMPDIR=/tmp
   for w in $PROF; do
-    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o $w -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --workload $w > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1 < /dev/null
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$w -o $w -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-cold --workload $w > $GRAFT_REPO_ROOT/gpurun_out/prof_$w.log 2>&1 < /dev/null
     f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$w -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && head -8 "$f"
   done
