@@ -131,7 +131,8 @@ class ShardedBackend:
             self._dev = dev
             self._stream = torch.cuda.Stream(device=dev)   # sweep, all-reduce and copies share it
             self._peer = None
-            if dist.get_backend(group) == "nccl":
+            import os
+            if dist.get_backend(group) == "nccl" and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
                 with torch.cuda.device(dev), torch.cuda.stream(self._stream):
                     self._peer = PeerAllReduce.create(self.n_tokens + 1, group, dev)
 
@@ -199,7 +200,8 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
         import torch
         dev = rank if device is None else device
         backend = DeviceBackend(n_tokens, local, device=dev)
-        if dist.get_backend(group) == "nccl" and n_tokens <= 8192:
+        import os
+        if dist.get_backend(group) == "nccl" and n_tokens <= 8192 and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
             # fast path: the all-reduce happens INSIDE the library at the end of every sweep
             # (cfmm_set_peers), so find_arb_/route_ -- including the one-call native route! -- work on
             # the global market unchanged.  Falls through to ShardedBackend (RCCL) if unavailable.
