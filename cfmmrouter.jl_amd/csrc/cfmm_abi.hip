@@ -451,7 +451,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (ea && eb) c->pending.push_back({ea, eb, 0});
     }
     hipEvent_t ra = nullptr, rb = nullptr;
-    if (timed && !(inline_fold && c->rows_total > 0)) {
+    if (timed) {
         ra = take_event(c);
         rb = take_event(c);
         if (!ra || !rb) ra = rb = nullptr;
