@@ -399,7 +399,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             c->arrive_count += (unsigned long long)g.grid;
             a.arrive_target = c->arrive_count;
             grid += fold_blocks;
-            lds = std::max(lds, ((size_t)(g.block / 64) * kReduceCols + 1) * sizeof(double));
+            lds = std::max(lds, (size_t)(g.block / 64) * kReduceCols * sizeof(double));
         }
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)

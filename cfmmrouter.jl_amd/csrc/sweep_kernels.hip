@@ -599,8 +599,8 @@ __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __
 template <int BLOCK>
 __device__ __forceinline__ void fold_in_launch(const SweepArgs& a, int col_group)
 {
-    extern __shared__ double lds[];   // [BLOCK/64][8] fold scratch, then one flag word (no static LDS:
-    int& ok = *reinterpret_cast<int*>(lds + (BLOCK / 64) * kReduceCols); // the kernels may use all 160 KiB)
+    extern __shared__ double lds[];
+    __shared__ int ok;
     if (threadIdx.x == 0) {
         long long spins = 0;
         ok = 1;
