@@ -91,8 +91,6 @@ struct cfmm_ctx {
     int* d_tok_chunk_off = nullptr; // [n+1]
     double* d_chunk_sums = nullptr; // [n_chunks]
     int n_chunks = 0;
-    unsigned long long* d_arrive = nullptr; // in-launch fold: device arrival counter (monotonic)
-    unsigned long long arrive_count = 0;    // its value once every launch enqueued so far has completed
     // sharded operation (cfmm_set_peers): every host-pointer sweep ends with the one-shot peer
     // all-reduce of peer_allreduce.hip, so eval / find_arb / route return GLOBAL {Ψ, acc}
     std::vector<uint64_t> peers;  // device addresses of all ranks' symmetric buffers
@@ -114,7 +112,6 @@ struct cfmm_ctx {
     int64_t opt_nt_stores = 0;
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
-    int64_t opt_inline_fold = 0;   // 1: fold the partial rows inside the sweep launch (no second kernel)
     int64_t opt_univ3_coop = -1;   // -1 auto (by walk-list length), 0 lane-per-pool only, 1 wavefront-cooperative
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
     int64_t opt_spin_wait = 0;     // 1: host-pointer calls busy-poll the stream (measured: no gain over hipStreamSynchronize)
@@ -348,8 +345,6 @@ int ensure_geometry(cfmm_ctx* c)
         int rc = build_incidence(c);
         if (rc != CFMM_OK) return rc;
     }
-    HIP_TRY(c, hipMemset(c->d_arrive, 0, sizeof(unsigned long long))); // device-synchronous
-    c->arrive_count = 0;
     c->geometry_dirty = false;
     c->have_trades = false;
     c->have_out = false;
@@ -374,9 +369,6 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool timed = c->opt_time_kernels != 0 && c->pending.size() < (1u << 20); // harvest with cfmm_kernel_times
     const bool gb = global_bins(c);
     HIP_TRY(c, hipSetDevice(c->device));
-    // in-launch fold: only when the whole sweep is ONE launch and the fold is small
-    const bool inline_fold = c->opt_inline_fold != 0 && !gb && c->groups.size() == 1 && c->n <= 1024;
-    const int fold_blocks = (c->n + 1 + kReduceCols - 1) / kReduceCols;
     for (const Group& g : c->groups) {
         SweepArgs a;
         a.v = d_v;
@@ -388,19 +380,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
         a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
-        a.arrive = nullptr;
-        a.arrive_target = 0;
-        a.sweep_blocks = g.grid;
-        a.fold_out = d_out;
-        int grid = g.grid;
-        size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
-        if (inline_fold) {
-            a.arrive = c->d_arrive;
-            c->arrive_count += (unsigned long long)g.grid;
-            a.arrive_target = c->arrive_count;
-            grid += fold_blocks;
-            lds = std::max(lds, (size_t)(g.block / 64) * kReduceCols * sizeof(double));
-        }
+        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
             ea = take_event(c);
@@ -428,7 +408,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
                 }
             }
-            LaunchCfg cfg{g.block, grid, 1, lds, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, 1, lds, ea, eb};
             e = launch_multi(ma, cfg, materialize, c->stream);
         } else {
             const Segment& s = c->segs[(size_t)g.first];
@@ -436,7 +416,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
-            LaunchCfg cfg{g.block, grid, s.unroll, lds, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, s.unroll, lds, ea, eb};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN:
@@ -457,9 +437,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (!ra || !rb) ra = rb = nullptr;
         if (ra && (gb || c->rows_total == 0)) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
     }
-    if (inline_fold && c->rows_total > 0) {
-        // {Ψ, acc} were written by the sweep launch's own fold blocks
-    } else if (c->rows_total > 0) {
+    if (c->rows_total > 0) {
         hipError_t e;
         if (gb) { // pull Ψ per token over the incidence list, then fold the dual-scalar column
             e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
@@ -588,8 +566,6 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     c->stream = c->own_stream;
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
-    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_arrive), sizeof(unsigned long long)));
-    HIP_TRY_C(hipMemset(c->d_arrive, 0, sizeof(unsigned long long)));
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double),
                             hipHostMallocMapped));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_stage), c->h_stage, 0) != hipSuccess) {
@@ -615,7 +591,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials);
     (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
     (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
-    (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums); (void)hipFree(c->d_arrive);
+    (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -648,7 +624,6 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "fuse_segments")) return &c->opt_fuse_segments;
     if (!std::strcmp(key, "zero_copy")) return &c->opt_zero_copy;
     if (!std::strcmp(key, "univ3_coop")) return &c->opt_univ3_coop;
-    if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     return nullptr;
 }

@@ -57,11 +57,6 @@ struct SweepArgs {
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int nt_stores;               // use non-temporal stores for Delta/Lambda
-    // in-launch row fold (null arrive: a separate reduce_partials launch folds the rows instead)
-    unsigned long long* arrive;  // device-scope arrival counter, monotonic across launches
-    unsigned long long arrive_target; // value it reaches when every sweep block of THIS launch has arrived
-    int sweep_blocks;            // blocks [0, sweep_blocks) sweep; the blocks after them fold 8 columns each
-    double* fold_out;            // [n+1] {Ψ, acc}
 };
 
 // One launch over up to kMaxMulti segments (sweep_multi).

@@ -542,108 +542,9 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     }
 }
 
-// Folds the per-block partial rows: out[j] = sum_rows partials[row][j].  One block owns
-// kReduceCols adjacent columns; its lanes are BLOCK/8 row-lanes x 8 columns (fold_columns).
-template <int BLOCK>
-__device__ __forceinline__ void fold_columns(const double* __restrict__ partials, int rows, int n1,
-                                             double* __restrict__ out, int col_group, double* red /* [BLOCK/64][8] */)
-{
-    // lane = (row-lane r, column c): 8 columns (one 64 B line of a row) x BLOCK/8 row-lanes.  A
-    // wavefront holds 8 row-lanes x 8 columns; row-lanes are folded by a fixed shuffle tree, the
-    // wavefronts by a fixed-order LDS pass.
-    constexpr int kRowLanes = BLOCK / kReduceCols;
-    constexpr int kWaves = BLOCK / 64;
-    constexpr int kBatch = 4;   // independent loads in flight per lane
-    const int c = threadIdx.x % kReduceCols;
-    const int r = threadIdx.x / kReduceCols;
-    const int col = col_group * kReduceCols + c;
-    double s = 0.0;
-    if (col < n1) {
-        const double* p = partials + col;
-        int row = r;
-        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
-            double x[kBatch];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) s += x[b];
-        }
-        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
-    }
-#pragma unroll
-    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
-    __syncthreads();
-    if (threadIdx.x < kReduceCols && col < n1) {
-        double tsum = red[c];
-        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
-        out[col] = tsum;
-    }
-}
-
-__global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int rows,
-                                                                int n1, double* __restrict__ out)
-{
-    __shared__ double red[(kReduceBlock / 64) * kReduceCols];
-    fold_columns<kReduceBlock>(partials, rows, n1, out, blockIdx.x, red);
-}
-
-// In-launch fold: the blocks after the sweep blocks wait until every sweep block of this launch
-// has published its partial row, then fold 8 columns each -- the row fold without a second launch
-// and its kernel boundary.  Hand-off per cdna_hip_programming.md G16: producer = per-wave
-// vmcnt(0), __syncthreads, one-lane agent-scope release + vmcnt(0), relaxed agent-scope arrival
-// add; consumer = one-lane relaxed poll, ONE agent-scope acquire, __syncthreads, plain loads.
-// Sweep blocks never wait on anything, so the fold blocks' spin cannot deadlock whatever the
-// residency; it is bounded anyway (NaN output on timeout).
-template <int BLOCK>
-__device__ __forceinline__ void fold_in_launch(const SweepArgs& a, int col_group)
-{
-    extern __shared__ double lds[];
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        long long spins = 0;
-        ok = 1;
-        while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.arrive_target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > 20000000ll) { ok = 0; break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (ok) {
-        fold_columns<BLOCK>(a.partials, a.sweep_blocks, a.n + 1, a.fold_out, col_group, lds);
-    } else {
-        const int col = col_group * kReduceCols + (int)threadIdx.x;
-        if (threadIdx.x < kReduceCols && col < a.n + 1) a.fold_out[col] = __builtin_nan("");
-    }
-}
-
-__device__ __forceinline__ void publish_row(const SweepArgs& a)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's row (and trade) stores are out
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    if constexpr (!GBINS) {
-        if (a.arrive) {
-            if ((int)blockIdx.x >= a.sweep_blocks) {
-                fold_in_launch<BLOCK>(a, (int)blockIdx.x - a.sweep_blocks);
-                return;
-            }
-            sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, blockIdx.x, a.sweep_blocks, blockIdx.x);
-            publish_row(a);
-            return;
-        }
-    }
     sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, blockIdx.x, gridDim.x, blockIdx.x);
 }
 
@@ -653,14 +554,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
-    const bool in_launch_fold = !GBINS && ma.common.arrive != nullptr;
-    if (in_launch_fold && (int)blockIdx.x >= ma.common.sweep_blocks) {
-        fold_in_launch<BLOCK>(ma.common, (int)blockIdx.x - ma.common.sweep_blocks);
-        return;
-    }
     const int sidx = blockIdx.x % ma.nseg;
     const int local = blockIdx.x / ma.nseg;
-    const int nblocks = (in_launch_fold ? ma.common.sweep_blocks : (int)gridDim.x) / ma.nseg;
+    const int nblocks = gridDim.x / ma.nseg;
     const MultiSeg& sg = ma.seg[sidx];
     SweepArgs a = ma.common;
     a.m = sg.m;
@@ -683,7 +579,47 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         }
         break;
     }
-    if (in_launch_fold) publish_row(ma.common);
+}
+
+// Folds the per-block partial rows: out[j] = sum_rows partials[row][j].  One block owns
+// kReduceCols adjacent columns; its 256 lanes are 16 row-lanes x 16 columns.  Each lane sums
+// its rows in increasing order, the 16 row-lanes are then folded in increasing order.
+__global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int rows,
+                                                                int n1, double* __restrict__ out)
+{
+    // lane = (row-lane r, column c): 8 columns (one 64 B line of a row) x 128 row-lanes.  A
+    // wavefront holds 8 row-lanes x 8 columns; row-lanes are folded by a fixed shuffle tree, the
+    // 16 wavefronts by a fixed-order LDS pass.
+    constexpr int kRowLanes = kReduceBlock / kReduceCols;
+    constexpr int kWaves = kReduceBlock / 64;
+    constexpr int kBatch = 4;   // independent loads in flight per lane
+    __shared__ double red[kWaves][kReduceCols];
+    const int c = threadIdx.x % kReduceCols;
+    const int r = threadIdx.x / kReduceCols;
+    const int col = blockIdx.x * kReduceCols + c;
+    double s = 0.0;
+    if (col < n1) {
+        const double* p = partials + col;
+        int row = r;
+        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
+            double x[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) s += x[b];
+        }
+        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
+    }
+#pragma unroll
+    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < kReduceCols) red[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < kReduceCols && col < n1) {
+        double tsum = red[0][c];
+        for (int k = 1; k < kWaves; ++k) tsum += red[k][c];
+        out[col] = tsum;
+    }
 }
 
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat

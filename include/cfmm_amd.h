@@ -64,8 +64,7 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
 
 /* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 512 | 1024 threads),
  * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
- * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "inline_fold" (1: the partial rows are folded
- * by extra blocks of the sweep launch itself instead of a second kernel), "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
+ * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
  * walks only, 1 wavefront-cooperative deep walks), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream), "zero_copy" (default 1: host-pointer calls
  * exchange v / Psi through mapped pinned memory instead of copy commands), "fuse_segments" (default 1: all
  * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate

@@ -659,33 +659,3 @@ def test_eight_shards_summed_equal_the_unsharded_sweep():
     assert rows == sum(len(b) for b in market)
     assert rel_to_max(psi_sum, psi_all) <= 1e-12
     assert abs(acc_sum - acc_all) <= 1e-11 * abs(acc_all)
-
-
-@pytest.mark.parametrize("shape", ["single_1024", "fused_512", "small_256"])
-def test_in_launch_fold_matches_separate_fold(shape):
-    """inline_fold=1: the row fold runs in extra blocks of the sweep launch (release/acquire hand-off
-    between blocks).  Many back-to-back sweeps with changing v: any stale read would show as a
-    mismatch against the two-kernel path."""
-    n = 256
-    if shape == "single_1024":
-        market = [synth.product_pools(600_000, n, seed=1)]
-    elif shape == "fused_512":
-        market = [synth.product_pools(300_000, n, seed=1), synth.geomean_pools(200_000, n, seed=2),
-                  synth.bounded_product_pools(100_000, n, seed=3)]
-    else:
-        market = [synth.product_pools(60_000, n, seed=1)]
-    a, b = cr.DeviceBackend(n, market), cr.DeviceBackend(n, market)
-    b.ctx.set_option("inline_fold", 1)
-    for k in range(120):
-        v = synth.sweep_prices(n, seed=k, spread=0.1 + 0.01 * k)
-        mat = k % 3 == 0
-        pa, aa = (a.find_arb if mat else a.eval)(v)
-        pb, ab = (b.find_arb if mat else b.eval)(v)
-        if shape == "single_1024":           # same fold geometry (1024-thread fold blocks): bit-identical
-            np.testing.assert_array_equal(pa, pb)
-            assert aa == ab
-        else:                                # 512 / 256-thread fold blocks: another fixed summation tree
-            assert rel_to_max(pb, pa) <= 1e-13 and abs(ab - aa) <= 1e-12 * abs(aa)
-    Da, La = a.trades() if mat else (None, None)
-    a.close()
-    b.close()
