@@ -198,6 +198,13 @@ int fat_grid_cap(const cfmm_ctx* c, int block)
     return (c->n > 1024 && c->n <= kMaxLdsTokens ? kResidentThreads / 2 : kResidentThreads) / block;
 }
 
+// Fused multi-family launches: 512 blocks of 512 threads in total measured best on config3
+// (19.9 us per step vs 21.9 at 1024 blocks and 21.4 at 256; bench.py --opt block=.. --opt max_grid=..).
+int fused_grid_cap(const cfmm_ctx* c, int block)
+{
+    return std::min(fat_grid_cap(c, block), kResidentThreads / 2 / block);
+}
+
 // Launch geometry for a segment of m pools.  Small markets: 256-thread blocks, one tile each
 // (enough blocks to cover 256 CUs).  Large markets: 1024-thread blocks, at most two per CU, each
 // striding over many tiles -- this keeps the number of partial rows (and the fold kernel) small.
@@ -302,7 +309,7 @@ int ensure_geometry(cfmm_ctx* c)
                 tiles = std::max<int64_t>(tiles, (sg.m + block - 1) / block);
             }
             const int64_t cap = std::max<int64_t>(
-                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kSmallBlock ? 2048 : fat_grid_cap(c, block))) / g.nseg);
+                1, (c->opt_max_grid > 0 ? c->opt_max_grid : (block == kSmallBlock ? 2048 : fused_grid_cap(c, block))) / g.nseg);
             const int per_seg = (int)std::min<int64_t>(tiles, cap);
             for (int k = 0; k < g.nseg; ++k) c->segs[first + k].grid = per_seg;
             g.grid = per_seg * g.nseg;
