@@ -158,11 +158,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, rendezvous on
+        # 127.0.0.1 (the container hostname may not resolve).  Same command line, re-executed under torchrun.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+        raise SystemExit(f"[rank {rank}/{world}] bench.py needs an MI355X; there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"[rank {rank}/{world}] local rank {local_rank} has no GPU: {torch.cuda.device_count()} visible "
+                         f"(one rank per GPU; RCCL does not share a device between ranks)")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun even N=1 goes through RCCL
     if use_dist:

@@ -12,6 +12,7 @@
 #include "lbfgsb.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -96,8 +97,12 @@ struct cfmm_ctx {
     std::vector<uint64_t> peers;  // device addresses of all ranks' symmetric buffers
     int peer_rank = 0;
     uint64_t peer_seq = 0;
-    double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out
+    double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out, then one uint64 completion flag
     double* d_stage = nullptr;    // device address of h_stage
+    unsigned* d_sync = nullptr;   // [kSyncWords] arrival counters of the in-launch fold (zero between launches)
+    uint64_t flag_seq = 0;        // host-visible completion flag: value the NEXT flagged sweep will raise
+    bool last_inline = false;     // the latest enqueue_sweep folded inside the sweep launch
+    bool last_flagged = false;    // ... and raises the host flag (the caller may poll it instead of the stream)
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
     bool have_out = false;
     bool have_trades = false;
@@ -109,12 +114,16 @@ struct cfmm_ctx {
     int64_t opt_unroll = 0;      // 0 = auto
     int64_t opt_bin_copies = 0;  // 0 = auto, 1 = one shared copy, 2 = one copy per wavefront
     int64_t opt_time_kernels = 0;
-    int64_t opt_nt_stores = 0;
+    int64_t opt_nt_stores = 2;     // trade stores: 0 plain, 1 non-temporal, 2 write-through (default; -1..-2 us per 1M-pool sweep)
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
     int64_t opt_univ3_coop = -1;   // -1 auto (by walk-list length), 0 lane-per-pool only, 1 wavefront-cooperative
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
     int64_t opt_spin_wait = 0;     // 1: host-pointer calls busy-poll the stream (measured: no gain over hipStreamSynchronize)
+    int64_t opt_inline_fold = 0;   // 1: partial rows are folded inside the sweep launch (single-launch evaluations, n <= kMaxFoldTokens);
+                                   //    measured 1-3 us per step SLOWER than the separate fold launch, kept as an option
+    int64_t opt_host_flag = 1;     // 1: zero-copy host-pointer sweeps end by raising a flag in mapped host memory that the
+                                   //    caller polls, instead of waiting for the stream (saves the end-of-kernel + signal path)
 
     // kernel timing
     std::vector<hipEvent_t> ev_pool;
@@ -372,12 +381,19 @@ hipEvent_t take_event(cfmm_ctx* c)
 }
 
 // Enqueue one full evaluation on c->stream: every segment's sweep, then the row fold.
-int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize)
+int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_flag = false)
 {
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
     const bool timed = c->opt_time_kernels != 0 && c->pending.size() < (1u << 20); // harvest with cfmm_kernel_times
     const bool gb = global_bins(c);
+    // One launch per evaluation: the partial rows are folded by extra blocks of that launch.
+    const bool inline_fold = c->opt_inline_fold != 0 && !gb && c->groups.size() == 1 && c->rows_total > 0 &&
+                             c->n <= kMaxFoldTokens && c->d_sync != nullptr;
+    // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
+    const bool flagged = want_host_flag && !gb && c->rows_total > 0 && c->d_sync != nullptr;
+    c->last_inline = inline_fold;
+    c->last_flagged = flagged;
     HIP_TRY(c, hipSetDevice(c->device));
     for (const Group& g : c->groups) {
         SweepArgs a;
@@ -390,6 +406,11 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
         a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
+        a.fold_blocks = inline_fold ? (c->n + 1 + kReduceCols - 1) / kReduceCols : 0;
+        a.sync = c->d_sync;
+        a.fold_out = d_out;
+        a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
+        a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
@@ -445,21 +466,25 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         ra = take_event(c);
         rb = take_event(c);
         if (!ra || !rb) ra = rb = nullptr;
-        if (ra && (gb || c->rows_total == 0)) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
+        if (ra && !inline_fold && (gb || c->rows_total == 0)) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
     }
-    if (c->rows_total > 0) {
+    if (inline_fold) {
+        // nothing to launch: the sweep launch has already produced d_out
+    } else if (c->rows_total > 0) {
         hipError_t e;
         if (gb) { // pull Ψ per token over the incidence list, then fold the dual-scalar column
             e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
                               c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->d_partials, (int)c->rows_total, c->stream);
         } else {
-            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, ra, rb);
+            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, c->groups.back().block, ra, rb,
+                              c->d_sync, flagged ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr,
+                              flagged ? ++c->flag_seq : 0);
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
     }
-    if (ra && rb) {
+    if (ra && rb && !inline_fold) {
         if (gb || c->rows_total == 0) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
@@ -495,12 +520,27 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
         rc = cfmm_peer_allreduce(c->stream, c->peers.data(), (int32_t)c->peers.size(), c->peer_rank, c->n + 1, seq, out_dst);
         if (rc != CFMM_OK) return fail(c, rc, "cfmm_peer_allreduce launch failed");
     } else {
-        int rc = enqueue_sweep(c, v_src, out_dst, materialize);
+        int rc = enqueue_sweep(c, v_src, out_dst, materialize, zero_copy && c->opt_host_flag != 0);
         if (rc != CFMM_OK) return rc;
     }
     if (!zero_copy)
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (c->opt_spin_wait != 0) {
+    bool flag_seen = false;
+    if (c->peers.empty() && c->last_flagged) {
+        // The last fold block wrote {Ψ, acc} through to this pinned buffer and then raised the flag
+        // (PCIe posted writes stay ordered): poll it instead of waiting for the kernel's end-of-pipe
+        // processing and its completion signal.  Bounded; falls back to a stream wait.
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_stage + 2 * c->n + 1);
+        const unsigned long long want = c->flag_seq;
+        for (long spins = 0; spins < 400000000L; ++spins) {
+            if (*flag == want) { flag_seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (flag_seen) {
+        // results are on the host; the kernel itself retires in stream order behind us
+    } else if (c->opt_spin_wait != 0) {
         // busy-poll the stream instead of a blocking wait: the evaluation is ~30 us long and the
         // caller (an L-BFGS-B step) has nothing else to do meanwhile
         hipError_t q;
@@ -510,14 +550,25 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->last_out.assign(h_out, h_out + c->n + 1);
-    if (!c->peers.empty() && c->last_out[0] != c->last_out[0])
-        return fail(c, CFMM_ERR_STATE, "peer all-reduce timed out: a rank did not publish its {psi, acc}");
+    for (int j = 0; j <= c->n; ++j)
+        if (!std::isfinite(c->last_out[(size_t)j])) {
+            c->have_out = false;
+            if (!c->peers.empty())
+                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
+                                               "publish) or a shard overflowed", j);
+            return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: pool arithmetic overflowed, or the in-launch fold "
+                                           "timed out", j);
+        }
     c->have_out = true;
     return CFMM_OK;
 }
 
 int add_segment_common(cfmm_ctx* c, Segment&& s, const int32_t* Ai)
 {
+    if (s.m == 0) {   // an empty batch contributes no pools, no trades and no partial rows: not stored
+        free_segment(s);
+        return CFMM_OK;
+    }
     if (global_bins(c) && s.m > 0) s.h_ai.assign(Ai, Ai + 2 * s.m);
     c->segs.push_back(std::move(s));
     c->geometry_dirty = true;
@@ -576,8 +627,11 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     c->stream = c->own_stream;
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
-    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 1) * sizeof(double),
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 2) * sizeof(double),
                             hipHostMallocMapped));
+    std::memset(c->h_stage, 0, (size_t)(2 * c->n + 2) * sizeof(double));
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_sync), (size_t)kSyncWords * sizeof(unsigned)));
+    HIP_TRY_C(hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned)));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_stage), c->h_stage, 0) != hipSuccess) {
         (void)hipGetLastError();
         c->d_stage = nullptr; // fall back to explicit copies
@@ -598,7 +652,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& s : c->segs) free_segment(s);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials); (void)hipFree(c->d_sync);
     (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
     (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
     (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
@@ -635,6 +689,8 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "zero_copy")) return &c->opt_zero_copy;
     if (!std::strcmp(key, "univ3_coop")) return &c->opt_univ3_coop;
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
+    if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
+    if (!std::strcmp(key, "host_flag")) return &c->opt_host_flag;
     return nullptr;
 }
 

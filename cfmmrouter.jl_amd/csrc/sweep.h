@@ -11,7 +11,6 @@ constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
 constexpr int kMidBlock = 512;       // 8 wavefronts: fused multi-family launches (finer P/G interleave per CU)
 constexpr int kBigBlock = 1024;      // 16 wavefronts: single-family launches, few partial rows
 constexpr int kResidentThreads = 2048 * 256; // grid cap for the fat blocks: one machine of resident threads
-constexpr int kReduceBlock = 1024;
 constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
 constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 KiB LDS of a CU;
                                      // larger markets pull Ψ per token (sweep_body<..., GBINS=true>)
@@ -57,7 +56,21 @@ struct SweepArgs {
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int nt_stores;               // use non-temporal stores for Delta/Lambda
+    // In-launch row fold (fold_blocks > 0): the first fold_blocks blocks of the grid do not sweep;
+    // they wait until every sweeping block has published its partial row (write-through stores +
+    // arrival counters, no release fence) and then fold the rows into fold_out -- the work of
+    // reduce_partials without a second launch.  sync = kSyncWords zero-initialised uint32 words,
+    // left zero again by the launch.
+    int fold_blocks;
+    unsigned* sync;
+    double* fold_out;            // [n+1] {Ψ, acc}
+    unsigned long long* host_flag; // optional (mapped pinned host memory): set to host_seq by the last fold block
+    unsigned long long host_seq;   // once every fold block's part of fold_out has been written through to it
 };
+constexpr int kArriveShards = 16;    // arrival counters (one 128-B line each): block b arrives on shard b % 16
+constexpr int kSyncStride = 32;      // uint32 words per shard line
+constexpr int kSyncWords = (kArriveShards + 1) * kSyncStride;   // + the fold blocks' own "done" ticket line
+constexpr int kMaxFoldTokens = 1024; // above this the fold stays a separate launch (too many fold blocks)
 
 // One launch over up to kMaxMulti segments (sweep_multi).
 constexpr int kMaxMulti = 4;
@@ -106,8 +119,12 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
                          const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s);
 
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// `block` = the block size of the sweep launches that produced the rows (same summation order as the in-launch fold).
+// host_flag != null (needs sync): out is mapped host memory; the last fold block sets *host_flag = host_seq after
+// every block's part of out has been written through.
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, unsigned* sync = nullptr,
+                         unsigned long long* host_flag = nullptr, unsigned long long host_seq = 0);
 
 size_t sweep_lds_bytes(int n_pad, int copies, int block);
 hipError_t prepare_kernels(size_t max_lds_bytes);

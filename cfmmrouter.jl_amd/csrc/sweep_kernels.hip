@@ -407,9 +407,29 @@ struct UniV3CoopOps : UniV3Ops {
 // ---------------------------------------------------------------------------------------------
 // The sweep: src/router.jl:38-42 fused with :79-83 and :98-100
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_pair(double2* dst, double x, double y, int nt)
+// Agent-scope (write-through / L1-bypassing, `sc1`) accesses for data exchanged between blocks of
+// ONE launch: MI355X_MICROARCH.md "inter-workgroup visibility" -- 8-byte agent-scope atomics on both
+// sides are a valid hand-off without any fence.
+__device__ __forceinline__ void store_through(double* p, double x)
 {
-    if (nt) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_through(const double* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Trade stores (Δ, Λ: 16 B per lane, written once, never re-read by the sweep).  mode 0: plain
+// stores (the lines stay dirty in this XCD's L2 until evicted or until the end-of-kernel
+// write-back); 1: non-temporal; 2: write-through (`sc1`) -- the bytes leave during the sweep instead
+// of in a serial flush at its end (MI355X_MICROARCH.md, boundary row: + B / 6 TB/s for B dirty bytes).
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pair(double2* dst, double x, double y, int mode)
+{
+    if (mode == 2) {
+        d2v val = {x, y};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory");
+    } else if (mode == 1) {
         __builtin_nontemporal_store(x, &dst->x);
         __builtin_nontemporal_store(y, &dst->y);
     } else {
@@ -530,22 +550,159 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
+    const bool publish = !GBINS && a.fold_blocks > 0;    // the row is folded inside THIS launch
     for (int j = tid; j < n_cols; j += kBlock) {
         double s = bins[j];
         for (int c = 1; c < a.copies; ++c) s += bins[(size_t)c * a.n_pad + j];
-        row[j] = s;
+        if (publish) store_through(row + j, s);
+        else row[j] = s;
     }
     if (tid == 0) {
         double s = wsum[0];
         for (int w = 1; w < kWaves; ++w) s += wsum[w];
-        row[n_cols] = s;
+        if (publish) store_through(row + n_cols, s);
+        else row[n_cols] = s;
     }
+    if (publish) {
+        // Hand the row to the fold blocks of this launch: the row went out with write-through
+        // (agent-scope) stores, so no release fence -- a buffer_wbl2 here would also have to write
+        // back this XCD's share of the 32 MB of trade stores (measured 2.5x slower per step in
+        // round 1).  Every storing wavefront drains its own stores, then ONE lane arrives.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(a.sync + (row_id % kArriveShards) * kSyncStride, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row fold: out[j] = sum over rows of partials[row][j]  (src/router.jl:81-83, :98-100 summed over blocks)
+// ---------------------------------------------------------------------------------------------
+// One block owns kReduceCols adjacent columns (one 64 B line of every row).  lane = (row-lane r,
+// column c): a wavefront holds 8 row-lanes x 8 columns.  Each lane sums its rows in increasing
+// order (kBatch independent loads in flight), the row-lanes of a wavefront are folded by a fixed
+// shuffle tree, the wavefronts by a fixed-order LDS pass: bit-reproducible for a fixed geometry.
+// COHERENT: rows are read with agent-scope loads (they were published inside the same launch).
+template <int BLOCK, bool COHERENT>
+__device__ __forceinline__ double fold_columns(const double* partials, int rows, int n1, int colblock, double* red)
+{
+    constexpr int kRowLanes = BLOCK / kReduceCols;
+    constexpr int kWaves = BLOCK / 64;
+    constexpr int kBatch = 8;
+    const int c = threadIdx.x % kReduceCols;
+    const int r = threadIdx.x / kReduceCols;
+    const int col = colblock * kReduceCols + c;
+    double s = 0.0;
+    if (col < n1) {
+        const double* p = partials + col;
+        auto ld = [&](int row) -> double {
+            if constexpr (COHERENT) return load_through(p + (size_t)row * n1);
+            else return p[(size_t)row * n1];
+        };
+        int row = r;
+        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
+            double x[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) x[b] = ld(row + b * kRowLanes);
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) s += x[b];
+        }
+        for (; row < rows; row += kRowLanes) s += ld(row);
+    }
+#pragma unroll
+    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
+    __syncthreads();
+    double tsum = 0.0;
+    if (threadIdx.x < kReduceCols) {
+        tsum = red[c];
+        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
+    }
+    return tsum;   // valid in threads [0, kReduceCols) with col < n1
+}
+
+// Tail of a fold block: write its (up to) kReduceCols outputs and, when asked, take part in the
+// fold blocks' "done" ticket: the LAST fold block to get here (a) zeroes the arrival counters of an
+// in-launch fold for the next launch and (b) raises the host-visible completion flag.  For (b) the
+// outputs live in mapped host memory and are written with system-scope (write-through) stores that
+// every block drains before it takes its ticket, so the flag -- a later posted write on the same
+// PCIe path -- cannot overtake them.
+__device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double* out, unsigned* sync, int fold_blocks,
+                                            bool reset_arrivals, unsigned long long* host_flag,
+                                            unsigned long long host_seq)
+{
+    const int tid = threadIdx.x;
+    const int col = blockIdx.x * kReduceCols + tid;
+    if (tid < kReduceCols && col < n1) {
+        const double val = ok ? tsum : __builtin_nan("");
+        if (host_flag) __hip_atomic_store(out + col, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else out[col] = val;
+    }
+    if (!reset_arrivals && !host_flag) return;
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's outputs have left
+        if (tid == 0) {
+            unsigned* done = sync + kArriveShards * kSyncStride;
+            const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)fold_blocks - 1u) {         // last fold block: every output is out
+                if (reset_arrivals)
+                    for (int k = 0; k < kArriveShards; ++k)
+                        __hip_atomic_store(sync + k * kSyncStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (host_flag) __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// The fold blocks of a sweep launch (blockIdx.x < a.fold_blocks).  Wavefront 0 polls the arrival
+// counters (relaxed agent-scope loads, s_sleep between polls, bounded) until all `nprod` sweeping
+// blocks have published; the rows are then read with agent-scope loads (the producers stored
+// agent-scope: no acquire fence needed) and folded exactly as reduce_partials does.  The last fold
+// block to finish zeroes the counters again, so the next launch on the stream starts clean, and --
+// when the output lives in mapped host memory -- raises the host-visible completion flag.
+template <int BLOCK>
+__device__ __forceinline__ void fold_role(const SweepArgs& a, int nprod)
+{
+    extern __shared__ double lds[];
+    double* red = lds;                                   // [BLOCK/64][kReduceCols]
+    int* okp = reinterpret_cast<int*>(lds + (BLOCK / 64) * kReduceCols);
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        bool ok = true;
+        for (unsigned spins = 0;; ++spins) {
+            unsigned cnt = tid < kArriveShards
+                               ? __hip_atomic_load(a.sync + tid * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (cnt >= (unsigned)nprod) break;
+            if (spins > (1u << 22)) { ok = false; break; }   // seconds: a sweeping block died; poison the output
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (tid == 0) *okp = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = *okp != 0;
+    __syncthreads();                                     // okp shares no storage with red, but keep phases apart
+    const int n1 = a.n + 1;
+    const double tsum = fold_columns<BLOCK, true>(a.partials, nprod, n1, blockIdx.x, red);
+    fold_finish(tsum, ok, n1, a.fold_out, a.sync, a.fold_blocks, true, a.host_flag, a.host_seq);
 }
 
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, blockIdx.x, gridDim.x, blockIdx.x);
+    if constexpr (!GBINS) {
+        if ((int)blockIdx.x < a.fold_blocks) {
+            fold_role<BLOCK>(a, (int)gridDim.x - a.fold_blocks);
+            return;
+        }
+    }
+    const int fb = GBINS ? 0 : a.fold_blocks;
+    sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
 }
 
 // Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
@@ -554,9 +711,15 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
-    const int sidx = blockIdx.x % ma.nseg;
-    const int local = blockIdx.x / ma.nseg;
-    const int nblocks = gridDim.x / ma.nseg;
+    const int fb = GBINS ? 0 : ma.common.fold_blocks;
+    if (!GBINS && (int)blockIdx.x < fb) {
+        fold_role<BLOCK>(ma.common, (int)gridDim.x - fb);
+        return;
+    }
+    const int bidx = (int)blockIdx.x - fb;
+    const int sidx = bidx % ma.nseg;
+    const int local = bidx / ma.nseg;
+    const int nblocks = ((int)gridDim.x - fb) / ma.nseg;
     const MultiSeg& sg = ma.seg[sidx];
     SweepArgs a = ma.common;
     a.m = sg.m;
@@ -565,61 +728,32 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.gflow = sg.gflow;
     switch (sg.kind) {
     case 0:
-        sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, blockIdx.x);
+        sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
         break;
     case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
-        sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, blockIdx.x);
+        sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
         {   // the cooperative variant serves both shallow and deep segments here (no register cost:
             // the fused kernel's footprint is set by the GeometricMean branch)
             UniV3CoopOps ops;
             ops.p = sg.pools.u;
-            sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, blockIdx.x);
+            sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
         }
         break;
     }
 }
 
-// Folds the per-block partial rows: out[j] = sum_rows partials[row][j].  One block owns
-// kReduceCols adjacent columns; its 256 lanes are 16 row-lanes x 16 columns.  Each lane sums
-// its rows in increasing order, the 16 row-lanes are then folded in increasing order.
-__global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int rows,
-                                                                int n1, double* __restrict__ out)
+// The same fold as its own launch (several sweep launches per evaluation, or "inline_fold" = 0).
+// Launched with the sweep's block size, so both forms sum in the same order (bit-identical results).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int rows, int n1,
+                                                         double* __restrict__ out, unsigned* sync,
+                                                         unsigned long long* host_flag, unsigned long long host_seq)
 {
-    // lane = (row-lane r, column c): 8 columns (one 64 B line of a row) x 128 row-lanes.  A
-    // wavefront holds 8 row-lanes x 8 columns; row-lanes are folded by a fixed shuffle tree, the
-    // 16 wavefronts by a fixed-order LDS pass.
-    constexpr int kRowLanes = kReduceBlock / kReduceCols;
-    constexpr int kWaves = kReduceBlock / 64;
-    constexpr int kBatch = 4;   // independent loads in flight per lane
-    __shared__ double red[kWaves][kReduceCols];
-    const int c = threadIdx.x % kReduceCols;
-    const int r = threadIdx.x / kReduceCols;
-    const int col = blockIdx.x * kReduceCols + c;
-    double s = 0.0;
-    if (col < n1) {
-        const double* p = partials + col;
-        int row = r;
-        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
-            double x[kBatch];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) s += x[b];
-        }
-        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
-    }
-#pragma unroll
-    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < kReduceCols) red[wave][lane] = s;
-    __syncthreads();
-    if (threadIdx.x < kReduceCols && col < n1) {
-        double tsum = red[0][c];
-        for (int k = 1; k < kWaves; ++k) tsum += red[k][c];
-        out[col] = tsum;
-    }
+    __shared__ double red[(BLOCK / 64) * kReduceCols];
+    const double tsum = fold_columns<BLOCK, false>(partials, rows, n1, blockIdx.x, red);
+    fold_finish(tsum, true, n1, out, sync, (int)gridDim.x, false, host_flag, host_seq);
 }
 
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat
@@ -696,7 +830,10 @@ static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEve
 
 size_t sweep_lds_bytes(int n_pad, int copies, int block)
 {
-    return ((size_t)n_pad * (1 + copies) + block / 64) * sizeof(double);
+    // the fold blocks of the same launch need [block/64][kReduceCols] doubles + one flag word
+    const size_t sweep = (size_t)n_pad * (1 + copies) + block / 64;
+    const size_t fold = (size_t)(block / 64) * kReduceCols + 2;
+    return (sweep > fold ? sweep : fold) * sizeof(double);
 }
 
 template <class Ops>
@@ -719,7 +856,7 @@ static hipError_t set_lds_attr(size_t bytes)
 template <int B>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid), b(B);
+    dim3 g(c.grid + (ma.common.gflow ? 0 : ma.common.fold_blocks)), b(B);
     if (ma.common.gflow) {
         if (mat) launch_k(&sweep_multi<true, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
         else launch_k(&sweep_multi<false, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
@@ -761,7 +898,7 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
 template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid), b(B);
+    dim3 g(c.grid + (a.gflow ? 0 : a.fold_blocks)), b(B);
     hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
     if (a.gflow) { // large-market mode, one pool per lane per tile only
         if (mat) launch_k(&sweep_kernel<Ops, true, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);
@@ -808,11 +945,18 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
     return launch_any(ops, a, c, mat, s);
 }
 
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, hipEvent_t e0,
-                         hipEvent_t e1)
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
+                         hipEvent_t e0, hipEvent_t e1, unsigned* sync, unsigned long long* host_flag,
+                         unsigned long long host_seq)
 {
-    dim3 g((n1 + kReduceCols - 1) / kReduceCols), b(kReduceBlock);
-    launch_k(&reduce_partials, g, b, 0, s, e0, e1, partials, rows, n1, out);
+    dim3 g((n1 + kReduceCols - 1) / kReduceCols);
+    if (!sync) host_flag = nullptr;
+    if (block == kBigBlock)
+        launch_k(&reduce_partials<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+    else if (block == kMidBlock)
+        launch_k(&reduce_partials<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+    else
+        launch_k(&reduce_partials<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
     return hipGetLastError();
 }
 

@@ -1,0 +1,40 @@
+"""Option A/B runs on the GPU box: python scripts/exp.py WORKLOAD "k=v,k=v" "k=v" ...
+Prints, per option set: wall µs per step (K back-to-back device-resident sweeps, stream-synced),
+sweep-kernel and fold-kernel µs (hipExtLaunchKernel events), materialising and fused."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+import numpy as np, torch
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+import bench
+
+name = sys.argv[1]
+desc, n, build = bench.WORKLOADS[name]
+batches = build(0)
+v = synth.sweep_prices(n, seed=1234)
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+v_t = torch.from_numpy(v).to("cuda"); out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+K = int(os.environ.get("K", "200"))
+print(f"# {name}: {desc}")
+for spec in sys.argv[2:] or [""]:
+    be = cr.DeviceBackend(n, batches)
+    be.ctx.set_stream(stream.cuda_stream)
+    for kv in filter(None, spec.split(",")):
+        k, val = kv.split("="); be.ctx.set_option(k, int(val))
+    res = []
+    for mat in (True, False):
+        for _ in range(20): be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), mat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K): be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), mat)
+        torch.cuda.synchronize()
+        wall = 1e6 * (time.perf_counter() - t0) / K
+        be.ctx.set_option("time_kernels", 1); be.ctx.kernel_times()
+        for _ in range(K): be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), mat)
+        kt = be.ctx.kernel_times(); be.ctx.set_option("time_kernels", 0)
+        res.append((wall, 1e3 * kt["sweep_ms"] / K, 1e3 * kt["reduce_ms"] / K))
+    seg = [(s["block"], s["grid"]) for s in be.ctx.segments()]
+    (w1, s1, r1), (w2, s2, r2) = res
+    print(f"{spec or '(default)':45s} mat: step {w1:6.2f} sweep {s1:6.2f} fold {r1:5.2f} | fused: step {w2:6.2f} sweep {s2:6.2f} fold {r2:5.2f}  {seg}", flush=True)
+    be.close()

@@ -1,0 +1,175 @@
+"""GPU tests of the in-launch row fold (option "inline_fold") and the host-visible completion flag
+(option "host_flag"): the partial rows of a sweep are published with write-through stores and
+folded by extra blocks of the SAME launch (src/router.jl:81-83, :98-100 summed over blocks).
+
+The separate-launch fold (reduce_partials) sums the rows in exactly the same order, so the two
+forms must agree BIT FOR BIT; a stale or torn row read inside the launch shows up as a mismatch.
+Per MI355X_MICROARCH.md the hand-off is exercised back to back (the fold blocks' caches are warm
+with the previous sweep's rows), with different prices per sweep and with uneven per-block load.
+"""
+import numpy as np
+import pytest
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from helpers import oracle_sweep, rel_to_max
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, batches, **opts):
+    a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
+    a.ctx.set_option("inline_fold", 1)
+    b.ctx.set_option("inline_fold", 0)
+    for k, v in opts.items():
+        a.ctx.set_option(k, v)
+        b.ctx.set_option(k, v)
+    return a, b
+
+
+@pytest.mark.parametrize("shape", ["config2", "config3mini", "config4mini", "bounded", "tiny", "n1024"])
+def test_inline_fold_bitwise_equals_separate_fold(shape):
+    if shape == "config2":
+        n, batches = 64, [synth.product_pools(100_000, 64, seed=3)]
+    elif shape == "config3mini":
+        n, batches = 256, [synth.product_pools(200_000, 256, seed=3), synth.geomean_pools(150_001, 256, seed=4)]
+    elif shape == "config4mini":
+        n, batches = 512, [synth.product_pools(500_000, 512, seed=5)]
+    elif shape == "bounded":
+        n, batches = 256, [synth.bounded_product_pools(120_000, 256, seed=6)]
+    elif shape == "tiny":
+        n, batches = 2, [synth.product_pools(3, 2, seed=7)]
+    else:
+        n, batches = 1024, [synth.product_pools(70_000, 1024, seed=8)]
+    a, b = _pair(n, batches)
+    try:
+        rng = np.random.default_rng(11)
+        for it in range(40):   # back to back: the fold blocks re-read row addresses they read one sweep ago
+            v = synth.sweep_prices(n, seed=100 + it) * rng.uniform(0.5, 2.0)
+            for mat in (False, True):
+                pa = (a.find_arb if mat else a.eval)(v)
+                pb = (b.find_arb if mat else b.eval)(v)
+                if shape == "n1024":   # one LDS bin copy shared by the wavefronts: the sum order is not fixed
+                    assert rel_to_max(pa[0], pb[0]) <= 1e-14 and abs(pa[1] - pb[1]) <= 1e-12 * abs(pb[1])
+                else:
+                    np.testing.assert_array_equal(pa[0], pb[0])
+                    assert pa[1] == pb[1]
+        D, L, psi, acc = oracle_sweep(batches, n, v)
+        assert rel_to_max(pa[0], psi) <= 1e-12
+        Da, La = a.trades()
+        if shape != "config3mini":   # geomean trades differ from the oracle by a few ulp (tested elsewhere)
+            np.testing.assert_array_equal(Da, D)
+            np.testing.assert_array_equal(La, L)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_inline_fold_under_uneven_load():
+    """A deep-walk UniV3 segment next to a ProductTwoCoin segment: blocks of one launch finish at very
+    different times, and a second context streams on another stream meanwhile."""
+    n = 128
+    batches = [synth.product_pools(300_000, n, seed=21), synth.univ3_pools(40_000, n, 40, seed=22)]
+    a, b = _pair(n, batches)
+    noise = cr.DeviceBackend(256, [synth.product_pools(1_000_000, 256, seed=23)])
+    try:
+        import torch
+        vt = torch.from_numpy(synth.sweep_prices(256, seed=1)).cuda()
+        ot = torch.zeros(257, dtype=torch.float64, device="cuda")
+        for it in range(25):
+            for _ in range(4):   # asynchronous streaming load on the context's own stream
+                noise.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
+            v = synth.sweep_prices(n, seed=300 + it)
+            pa, pb = a.eval(v), b.eval(v)
+            np.testing.assert_array_equal(pa[0], pb[0])
+            assert pa[1] == pb[1]
+        torch.cuda.synchronize()
+    finally:
+        a.close()
+        b.close()
+        noise.close()
+
+
+def test_device_resident_sweeps_with_inline_fold():
+    """cfmm_sweep_dev (the bench's timed path): many launches in flight on one stream, each leaving the
+    arrival counters zero for the next."""
+    import torch
+    n = 256
+    batches = [synth.product_pools(500_000, n, seed=31), synth.geomean_pools(500_000, n, seed=32)]
+    a, b = _pair(n, batches)
+    try:
+        st = torch.cuda.Stream()
+        a.ctx.set_stream(st.cuda_stream)
+        b.ctx.set_stream(st.cuda_stream)
+        vs = [torch.from_numpy(synth.sweep_prices(n, seed=400 + k)).cuda() for k in range(8)]
+        oa = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in vs]
+        ob = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in vs]
+        torch.cuda.synchronize()
+        for rep in range(6):
+            for k, vt in enumerate(vs):
+                a.ctx.sweep_dev(vt.data_ptr(), oa[k].data_ptr(), rep % 2 == 0)
+            for k, vt in enumerate(vs):
+                b.ctx.sweep_dev(vt.data_ptr(), ob[k].data_ptr(), rep % 2 == 0)
+            st.synchronize()
+            for k in range(len(vs)):
+                assert torch.equal(oa[k], ob[k])
+        a.ctx.reset_stream()
+        b.ctx.reset_stream()
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("inline", [0, 1])
+def test_host_flag_and_stream_wait_agree(inline):
+    """Zero-copy host-pointer sweeps end when the last fold block raises a flag in mapped host memory
+    (option "host_flag", default on); waiting for the stream instead must give the same bits."""
+    n = 256
+    batches = [synth.product_pools(250_000, n, seed=41), synth.geomean_pools(250_000, n, seed=42)]
+    a = cr.DeviceBackend(n, batches)
+    b = cr.DeviceBackend(n, batches)
+    a.ctx.set_option("inline_fold", inline)
+    b.ctx.set_option("inline_fold", inline)
+    b.ctx.set_option("host_flag", 0)
+    try:
+        assert a.ctx.get_option("host_flag") == 1
+        for it in range(200):
+            v = synth.sweep_prices(n, seed=500 + it)
+            pa, pb = a.eval(v), b.eval(v)
+            np.testing.assert_array_equal(pa[0], pb[0])
+            assert pa[1] == pb[1]
+        # trades fetched right after a flagged sweep wait for the kernel itself
+        pa = a.find_arb(v)
+        pb = b.find_arb(v)
+        Da, La = a.trades()
+        Db, Lb = b.trades()
+        np.testing.assert_array_equal(Da, Db)
+        np.testing.assert_array_equal(La, Lb)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_empty_segment_through_the_abi_is_ignored():
+    """an m == 0 batch added through the C ABI must not leave an unwritten partial row."""
+    n = 16
+    for fuse, inline in ((0, 0), (0, 1), (1, 1)):
+        be = cr.DeviceBackend(n, [])
+        be.ctx.set_option("fuse_segments", fuse)
+        be.ctx.set_option("inline_fold", inline)
+        try:
+            pb = synth.product_pools(1000, n, seed=51)
+            empty = pb.slice(0, 0)
+            from cfmmrouter_amd.cfmms import _upload
+            _upload(be.ctx, empty)
+            _upload(be.ctx, pb)
+            _upload(be.ctx, empty)
+            assert be.ctx.pool_count == 1000 and len(be.ctx.segments()) == 1
+            v = synth.sweep_prices(n, seed=52)
+            psi, acc = be.find_arb(v)
+            D, L, psi_o, acc_o = oracle_sweep([pb], n, v)
+            assert rel_to_max(psi, psi_o) <= 1e-12
+            Dd, Ld = be.trades()
+            np.testing.assert_array_equal(Dd, D)
+        finally:
+            be.close()
