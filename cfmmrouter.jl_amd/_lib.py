@@ -83,6 +83,9 @@ def lib():
             pass
     L = C.CDLL(LIB_PATH)
     L.cfmm_ctx_create.argtypes = [C.c_int, C.c_int32, C.POINTER(_ctx)]
+    L.cfmm_ctx_create_multi.argtypes = [C.c_int32, _i32p, C.c_int32, C.POINTER(_ctx)]
+    L.cfmm_device_count.argtypes = [_ctx]
+    L.cfmm_device_count.restype = C.c_int32
     L.cfmm_ctx_destroy.argtypes = [_ctx]
     L.cfmm_ctx_destroy.restype = None
     L.cfmm_last_error.argtypes = [_ctx]
@@ -141,18 +144,29 @@ def ptr(a):
 
 
 class Context:
-    """RAII wrapper of a cfmm_ctx (one device, one pool store)."""
+    """RAII wrapper of a cfmm_ctx: one device and its pool store, or -- `device` a list of HIP
+    ordinals -- the single-process multi-device context of cfmm_ctx_create_multi (pools split in
+    contiguous blocks over the devices, {Ψ, acc} summed on the host)."""
 
-    def __init__(self, n_tokens: int, device: int = 0):
+    def __init__(self, n_tokens: int, device=0):
         self._L = lib()
         h = _ctx()
-        rc = self._L.cfmm_ctx_create(int(device), int(n_tokens), C.byref(h))
+        if isinstance(device, (list, tuple, np.ndarray)):
+            ids = np.ascontiguousarray(device, dtype=np.int32)
+            rc = self._L.cfmm_ctx_create_multi(int(ids.size), ptr(ids), int(n_tokens), C.byref(h))
+            self.device = [int(d) for d in ids]
+        else:
+            rc = self._L.cfmm_ctx_create(int(device), int(n_tokens), C.byref(h))
+            self.device = int(device)
         if rc != OK:
             self._h = None
             self._raise(rc, None)
         self._h = h
         self.n_tokens = int(n_tokens)
-        self.device = int(device)
+
+    @property
+    def device_count(self) -> int:
+        return int(self._L.cfmm_device_count(self._h))
 
     # -- errors --------------------------------------------------------------------------------
     def _raise(self, rc, h):

@@ -13,6 +13,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +67,25 @@ struct Group {
     int block = kSmallBlock;
     int grid = 0;       // total blocks of the launch
     int64_t row_off = 0;
+};
+
+} // namespace
+
+namespace {
+struct Workers {
+    // One persistent thread per shard >= 1 (shard 0 runs on the calling thread).  A call publishes
+    // {v, materialize} and bumps `go`; workers spin briefly on it (an L-BFGS-B evaluation follows
+    // the previous one within microseconds), then sleep on the condition variable.
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> go{0};
+    std::atomic<int> pending{0};
+    std::atomic<int> sleepers{0};
+    std::atomic<bool> quit{false};
+    const double* v = nullptr;
+    bool materialize = false;
+    std::vector<int> rc;
 };
 
 } // namespace
@@ -132,6 +155,13 @@ struct cfmm_ctx {
     std::vector<Pending> pending;
     int64_t t_sweep_n = 0, t_reduce_n = 0;
     double t_sweep_ms = 0, t_reduce_ms = 0;
+
+    // single-process multi-device parent (cfmm_ctx_create_multi): shards non-empty, no device state of its own
+    std::vector<cfmm_ctx*> shards;
+    struct ParentSeg { int kind; int64_t m; int64_t trade_off; };
+    std::vector<ParentSeg> psegs;          // one per cfmm_pools_add_* call with m > 0
+    std::unique_ptr<Workers> workers;
+    int64_t opt_multi_threads = 1;
 
     mutable std::string err = "";
 };
@@ -492,12 +522,18 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     return CFMM_OK;
 }
 
-int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
+int check_prices(cfmm_ctx* c, const double* v)
 {
     if (!v) return fail(c, CFMM_ERR_INVALID_ARG, "v is null");
     for (int j = 0; j < c->n; ++j)
         if (!(v[j] > 0.0) || !std::isfinite(v[j]))
             return fail(c, CFMM_ERR_INVALID_ARG, "v[%d] must be finite and > 0 (src/cfmms.jl:129)", j);
+    return CFMM_OK;
+}
+
+// First half of a host-pointer sweep: stage v, enqueue the evaluation (asynchronous).
+int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
+{
     HIP_TRY(c, hipSetDevice(c->device));
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
     double* h_out = c->h_stage + c->n;
@@ -525,6 +561,13 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
     }
     if (!zero_copy)
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return CFMM_OK;
+}
+
+// Second half: wait for {Ψ, acc} to be on the host and take them over into last_out.
+int host_sweep_end(cfmm_ctx* c)
+{
+    double* h_out = c->h_stage + c->n;
     bool flag_seen = false;
     if (c->peers.empty() && c->last_flagged) {
         // The last fold block wrote {Ψ, acc} through to this pinned buffer and then raised the flag
@@ -541,12 +584,12 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
     if (flag_seen) {
         // results are on the host; the kernel itself retires in stream order behind us
     } else if (c->opt_spin_wait != 0) {
-        // busy-poll the stream instead of a blocking wait: the evaluation is ~30 us long and the
-        // caller (an L-BFGS-B step) has nothing else to do meanwhile
+        // busy-poll the stream instead of a blocking wait
         hipError_t q;
         while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
         if (q != hipSuccess) return fail(c, CFMM_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
     } else {
+        HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->last_out.assign(h_out, h_out + c->n + 1);
@@ -561,6 +604,173 @@ int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
         }
     c->have_out = true;
     return CFMM_OK;
+}
+
+int single_host_sweep(cfmm_ctx* c, const double* v, bool materialize)
+{
+    int rc = host_sweep_begin(c, v, materialize);
+    return rc != CFMM_OK ? rc : host_sweep_end(c);
+}
+
+// ---- single-process multi-device context (cfmm_ctx_create_multi) ------------------------------
+// The parent context owns one ordinary single-device context per shard.  Pools of every batch are
+// split into contiguous blocks over the shards (no pool is replicated); a host-pointer sweep stages
+// the same v on every device, runs the shard sweeps concurrently (one host worker thread per shard,
+// or -- option "multi_threads" = 0 -- all launches from the calling thread, then all waits) and sums
+// the shards' {Ψ, acc} ON THE HOST in shard order: v comes from the host and Ψ returns to it on
+// every evaluation anyway, so the "all-reduce" of SURVEY 8e degenerates to N·(n+1) additions --
+// no peer access, no IPC, no torch.  One L-BFGS-B (cfmm_route) drives all shards.
+
+void shard_range(int64_t m, int d, int nd, int64_t& lo, int64_t& hi)
+{
+    const int64_t base = m / nd, rem = m % nd;
+    lo = d * base + std::min<int64_t>(d, rem);
+    hi = lo + base + (d < rem ? 1 : 0);
+}
+
+void worker_main(cfmm_ctx* parent, int d)
+{
+    Workers& w = *parent->workers;
+    cfmm_ctx* child = parent->shards[(size_t)d];
+    (void)hipSetDevice(child->device);
+    uint64_t seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (w.go.load(std::memory_order_acquire) == seen && !w.quit.load(std::memory_order_relaxed)) {
+            if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(w.mu);
+            w.sleepers.fetch_add(1);
+            w.cv.wait(lk, [&] { return w.go.load(std::memory_order_acquire) != seen || w.quit.load(); });
+            w.sleepers.fetch_sub(1);
+        }
+        if (w.quit.load()) return;
+        seen = w.go.load(std::memory_order_acquire);
+        w.rc[(size_t)d] = single_host_sweep(child, w.v, w.materialize);
+        w.pending.fetch_sub(1, std::memory_order_release);
+    }
+}
+
+int multi_host_sweep(cfmm_ctx* c, const double* v, bool materialize)
+{
+    const int nd = (int)c->shards.size();
+    std::vector<int>& rcs = c->workers->rc;
+    std::fill(rcs.begin(), rcs.end(), CFMM_OK);
+    if (c->opt_multi_threads != 0 && nd > 1) {
+        Workers& w = *c->workers;
+        if (w.threads.empty())
+            for (int d = 1; d < nd; ++d) w.threads.emplace_back(worker_main, c, d);
+        w.v = v;
+        w.materialize = materialize;
+        w.pending.store(nd - 1, std::memory_order_relaxed);
+        w.go.fetch_add(1, std::memory_order_release);
+        if (w.sleepers.load() > 0) {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.cv.notify_all();
+        }
+        rcs[0] = single_host_sweep(c->shards[0], v, materialize);
+        while (w.pending.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    } else {
+        for (int d = 0; d < nd; ++d) rcs[(size_t)d] = host_sweep_begin(c->shards[(size_t)d], v, materialize);
+        for (int d = 0; d < nd; ++d)
+            if (rcs[(size_t)d] == CFMM_OK) rcs[(size_t)d] = host_sweep_end(c->shards[(size_t)d]);
+    }
+    for (int d = 0; d < nd; ++d)
+        if (rcs[(size_t)d] != CFMM_OK) {
+            c->have_out = false;
+            return fail(c, rcs[(size_t)d], "shard %d (device %d): %s", d, c->shards[(size_t)d]->device,
+                        c->shards[(size_t)d]->err.c_str());
+        }
+    // the all-reduce: shard order, on the host
+    c->last_out.assign((size_t)c->n + 1, 0.0);
+    for (int d = 0; d < nd; ++d) {
+        const std::vector<double>& o = c->shards[(size_t)d]->last_out;
+        for (int j = 0; j <= c->n; ++j) c->last_out[(size_t)j] += o[(size_t)j];
+    }
+    c->have_out = true;
+    c->have_trades = materialize;
+    return CFMM_OK;
+}
+
+
+// ---- multi-device parents: pool upload and trade download across the shards -------------------
+void pop_last_segment(cfmm_ctx* child)
+{
+    (void)hipSetDevice(child->device);
+    (void)hipStreamSynchronize(child->stream);
+    free_segment(child->segs.back());
+    child->segs.pop_back();
+    child->geometry_dirty = true;
+    child->have_out = child->have_trades = false;
+}
+
+// Run add(child, d, lo, hi) on every shard with a non-empty block [lo, hi) of the m pools; all or nothing.
+template <class F>
+int multi_add(cfmm_ctx* c, int kind, int64_t m, F add)
+{
+    if (m < 0) return fail(c, CFMM_ERR_INVALID_ARG, "negative pool count");
+    if (m == 0) return CFMM_OK;
+    const int nd = (int)c->shards.size();
+    std::vector<int> added;
+    for (int d = 0; d < nd; ++d) {
+        int64_t lo, hi;
+        shard_range(m, d, nd, lo, hi);
+        if (hi == lo) continue;
+        cfmm_ctx* child = c->shards[(size_t)d];
+        const int rc = add(child, lo, hi);
+        if (rc != CFMM_OK) {
+            fail(c, rc, "pools [%lld, %lld) -> shard %d (device %d): %s", (long long)lo, (long long)hi, d, child->device,
+                 child->err.c_str());
+            for (int a : added) pop_last_segment(c->shards[(size_t)a]);
+            return rc;
+        }
+        added.push_back(d);
+    }
+    c->psegs.push_back({kind, m, c->m_total});
+    c->m_total += m;
+    c->have_out = c->have_trades = false;
+    return CFMM_OK;
+}
+
+// child segment index that holds shard d's block of parent segment `pseg` (-1: that block is empty)
+int child_segment(const cfmm_ctx* c, int pseg, int d)
+{
+    const int nd = (int)c->shards.size();
+    int idx = 0;
+    for (int k = 0; k <= pseg; ++k) {
+        int64_t lo, hi;
+        shard_range(c->psegs[(size_t)k].m, d, nd, lo, hi);
+        if (k == pseg) return hi > lo ? idx : -1;
+        if (hi > lo) ++idx;
+    }
+    return -1;
+}
+
+int multi_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t count, double* Delta, double* Lambda)
+{
+    if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb first");
+    if (seg < 0 || seg >= (int32_t)c->psegs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+    const int64_t m = c->psegs[(size_t)seg].m;
+    if (first < 0 || count < 0 || first + count > m) return fail(c, CFMM_ERR_INVALID_ARG, "row range out of bounds");
+    const int nd = (int)c->shards.size();
+    for (int d = 0; d < nd; ++d) {
+        int64_t lo, hi;
+        shard_range(m, d, nd, lo, hi);
+        const int64_t a = std::max(lo, first), b = std::min(hi, first + count);
+        if (b <= a) continue;
+        cfmm_ctx* child = c->shards[(size_t)d];
+        const int rc = cfmm_get_trades_range(child, child_segment(c, seg, d), a - lo, b - a,
+                                             Delta ? Delta + 2 * (a - first) : nullptr,
+                                             Lambda ? Lambda + 2 * (a - first) : nullptr);
+        if (rc != CFMM_OK) return fail(c, rc, "shard %d: %s", d, child->err.c_str());
+    }
+    return CFMM_OK;
+}
+
+int host_sweep(cfmm_ctx* c, const double* v, bool materialize)
+{
+    int rc = check_prices(c, v);
+    if (rc != CFMM_OK) return rc;
+    return c->shards.empty() ? single_host_sweep(c, v, materialize) : multi_host_sweep(c, v, materialize);
 }
 
 int add_segment_common(cfmm_ctx* c, Segment&& s, const int32_t* Ai)
@@ -644,9 +854,52 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     return CFMM_OK;
 }
 
+int cfmm_ctx_create_multi(int32_t n_devices, const int32_t* device_ids, int32_t n_tokens, cfmm_ctx** out)
+{
+    if (!out) return fail(nullptr, CFMM_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64 || !device_ids)
+        return fail(nullptr, CFMM_ERR_INVALID_ARG, "n_devices must be in [1, 64] and device_ids non-null");
+    if (n_tokens > kMaxLdsTokens)
+        return fail(nullptr, CFMM_ERR_UNSUPPORTED, "multi-device contexts are limited to n_tokens <= %d", kMaxLdsTokens);
+    cfmm_ctx* c = new cfmm_ctx();
+    c->device = -1;
+    c->n = n_tokens;
+    c->n_pad = (n_tokens + 1) & ~1;
+    c->workers.reset(new Workers());
+    c->workers->rc.assign((size_t)n_devices, CFMM_OK);
+    for (int d = 0; d < n_devices; ++d) {
+        cfmm_ctx* child = nullptr;
+        int rc = cfmm_ctx_create(device_ids[d], n_tokens, &child);   // validates the ordinal, the arch, n_tokens
+        if (rc != CFMM_OK) {
+            cfmm_ctx_destroy(c);
+            return rc;   // g_create_error already holds the message
+        }
+        c->shards.push_back(child);
+    }
+    *out = c;
+    return CFMM_OK;
+}
+
+int32_t cfmm_device_count(const cfmm_ctx* c) { return c ? (c->shards.empty() ? 1 : (int32_t)c->shards.size()) : 0; }
+
 void cfmm_ctx_destroy(cfmm_ctx* c)
 {
     if (!c) return;
+    if (c->workers) {
+        Workers& w = *c->workers;
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.quit.store(true);
+            w.cv.notify_all();
+        }
+        for (auto& t : w.threads) t.join();
+    }
+    if (!c->shards.empty() || c->device < 0) {
+        for (cfmm_ctx* child : c->shards) cfmm_ctx_destroy(child);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
@@ -661,9 +914,14 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     delete c;
 }
 
+#define CFMM_SINGLE_ONLY(c, what)                                                                     \
+    if (!(c)->shards.empty() || (c)->device < 0)                                                      \
+        return fail(c, CFMM_ERR_UNSUPPORTED, what " is not available on a multi-device context (host-pointer calls only)")
+
 int cfmm_set_stream(cfmm_ctx* c, void* hip_stream)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_set_stream");
     c->stream = static_cast<hipStream_t>(hip_stream); // NULL is HIP's default (null) stream
     return CFMM_OK;
 }
@@ -671,6 +929,7 @@ int cfmm_set_stream(cfmm_ctx* c, void* hip_stream)
 int cfmm_reset_stream(cfmm_ctx* c)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_reset_stream");
     c->stream = c->own_stream;
     return CFMM_OK;
 }
@@ -691,6 +950,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
     if (!std::strcmp(key, "host_flag")) return &c->opt_host_flag;
+    if (!std::strcmp(key, "multi_threads")) return &c->opt_multi_threads;
     return nullptr;
 }
 
@@ -707,6 +967,11 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
     if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == 2))
         return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 (shared) or 2 (per wavefront)");
     *slot = value;
+    if (slot != &c->opt_multi_threads)
+        for (cfmm_ctx* child : c->shards) {
+            int rc = cfmm_set_option(child, key, value);
+            if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
+        }
     if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
         slot == &c->opt_geomean_exact)
         c->geometry_dirty = true;
@@ -727,6 +992,10 @@ int cfmm_pools_add_product(cfmm_ctx* c, int64_t m, const double* R, const double
     if (!c) return CFMM_ERR_INVALID_ARG;
     int rc = check_two_coin(c, m, R, gamma, Ai);
     if (rc != CFMM_OK) return rc;
+    if (!c->shards.empty())
+        return multi_add(c, CFMM_KIND_PRODUCT, m, [&](cfmm_ctx* child, int64_t lo, int64_t hi) {
+            return cfmm_pools_add_product(child, hi - lo, R + 2 * lo, gamma + lo, Ai + 2 * lo);
+        });
     HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
     s.kind = CFMM_KIND_PRODUCT;
@@ -749,6 +1018,10 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
     for (int64_t i = 0; i < m; ++i)
         if (!finite_pos(w[2 * i]) || !finite_pos(w[2 * i + 1]))
             return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: weights must be finite and > 0", (long long)i);
+    if (!c->shards.empty())
+        return multi_add(c, CFMM_KIND_GEOMEAN, m, [&](cfmm_ctx* child, int64_t lo, int64_t hi) {
+            return cfmm_pools_add_geomean(child, hi - lo, R + 2 * lo, w + 2 * lo, gamma + lo, Ai + 2 * lo);
+        });
     // v-independent pieces of the log-space closed forms (sweep_kernels.hip, GeoMeanLogOps)
     std::vector<double2> lR((size_t)m);
     std::vector<double> etas((size_t)m);
@@ -778,6 +1051,16 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
     if (m > 0 && (!current_price || !gamma || !Ai || !tick_off || !lower_ticks || !liquidity))
         return fail(c, CFMM_ERR_INVALID_ARG, "null pool array");
     if (m > 0 && tick_off[0] != 0) return fail(c, CFMM_ERR_INVALID_ARG, "tick_off[0] must be 0");
+    if (!c->shards.empty()) {
+        for (int64_t i = 0; i < m; ++i)
+            if (tick_off[i + 1] < tick_off[i]) return fail(c, CFMM_ERR_INVALID_ARG, "tick_off must be non-decreasing");
+        return multi_add(c, CFMM_KIND_UNIV3, m, [&](cfmm_ctx* child, int64_t lo, int64_t hi) {
+            std::vector<int64_t> off((size_t)(hi - lo + 1));
+            for (int64_t i = lo; i <= hi; ++i) off[(size_t)(i - lo)] = tick_off[i] - tick_off[lo];   // CSR rebased to the block
+            return cfmm_pools_add_univ3(child, hi - lo, current_price + lo, gamma + lo, Ai + 2 * lo, off.data(),
+                                        lower_ticks + tick_off[lo], liquidity + tick_off[lo]);
+        });
+    }
     const int64_t T = m > 0 ? tick_off[m] : 0;
     if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
     std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
@@ -892,6 +1175,13 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
 int cfmm_pools_clear(cfmm_ctx* c)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {
+        for (cfmm_ctx* child : c->shards) cfmm_pools_clear(child);
+        c->psegs.clear();
+        c->m_total = 0;
+        c->have_out = c->have_trades = false;
+        return CFMM_OK;
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->segs) free_segment(s);
@@ -908,6 +1198,7 @@ int64_t cfmm_pools_count(const cfmm_ctx* c)
     if (!c) return 0;
     int64_t m = 0;
     for (auto& s : c->segs) m += s.m;
+    for (auto& ps : c->psegs) m += ps.m;
     return m;
 }
 
@@ -933,6 +1224,7 @@ int cfmm_eval(cfmm_ctx* c, const double* v, double* psi_out, double* acc_out)
 int cfmm_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t count, double* Delta, double* Lambda)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) return multi_get_trades_range(c, seg, first, count, Delta, Lambda);
     if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb first");
     if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
     const Segment& s = c->segs[(size_t)seg];
@@ -952,6 +1244,15 @@ int cfmm_get_trades(cfmm_ctx* c, double* Delta, double* Lambda)
     if (!c) return CFMM_ERR_INVALID_ARG;
     if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb first");
     if (c->m_total == 0) return CFMM_OK;
+    if (!c->shards.empty()) {
+        for (size_t k = 0; k < c->psegs.size(); ++k) {
+            const auto& ps = c->psegs[k];
+            const int rc = multi_get_trades_range(c, (int32_t)k, 0, ps.m, Delta ? Delta + 2 * ps.trade_off : nullptr,
+                                                  Lambda ? Lambda + 2 * ps.trade_off : nullptr);
+            if (rc != CFMM_OK) return rc;
+        }
+        return CFMM_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (Delta) HIP_TRY(c, hipMemcpy(Delta, c->d_delta, (size_t)c->m_total * sizeof(double2), hipMemcpyDeviceToHost));
@@ -978,6 +1279,7 @@ int cfmm_dual_value(cfmm_ctx* c, double* acc)
 int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materialize)
 {
     if (!c || !d_v || !d_out) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_sweep_dev");
     c->have_out = false; // results live on the device; the host copy is stale
     return enqueue_sweep(c, d_v, d_out, materialize != 0);
 }
@@ -985,6 +1287,7 @@ int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materializ
 int cfmm_trades_dev(cfmm_ctx* c, const double** d_delta, const double** d_lambda)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_trades_dev");
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
     if (d_delta) *d_delta = reinterpret_cast<const double*>(c->d_delta);
@@ -996,6 +1299,22 @@ int cfmm_kernel_times(cfmm_ctx* c, int64_t* sweep_launches, double* sweep_ms, in
                       double* reduce_ms)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {   // totals over the shards
+        int64_t sn = 0, rn = 0;
+        double sm = 0, rm = 0;
+        for (cfmm_ctx* child : c->shards) {
+            int64_t a = 0, b = 0;
+            double x = 0, y = 0;
+            int rc = cfmm_kernel_times(child, &a, &x, &b, &y);
+            if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
+            sn += a; rn += b; sm += x; rm += y;
+        }
+        if (sweep_launches) *sweep_launches = sn;
+        if (sweep_ms) *sweep_ms = sm;
+        if (reduce_launches) *reduce_launches = rn;
+        if (reduce_ms) *reduce_ms = rm;
+        return CFMM_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& p : c->pending) {
@@ -1018,6 +1337,7 @@ int cfmm_kernel_times(cfmm_ctx* c, int64_t* sweep_launches, double* sweep_ms, in
 int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_set_peers");
     if (world == 0) { // back to single-GPU operation
         c->peers.clear();
         return CFMM_OK;
@@ -1146,12 +1466,26 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     return CFMM_OK;
 }
 
-int32_t cfmm_segment_count(const cfmm_ctx* c) { return c ? (int32_t)c->segs.size() : 0; }
+int32_t cfmm_segment_count(const cfmm_ctx* c)
+{
+    return c ? (int32_t)(c->shards.empty() ? c->segs.size() : c->psegs.size()) : 0;
+}
 
 int cfmm_segment_info(const cfmm_ctx* c, int32_t seg, int32_t* kind, int64_t* m, int32_t* block, int32_t* grid,
                       int32_t* unroll)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {   // kind and size of the whole segment; launch geometry of shard 0's block
+        if (seg < 0 || seg >= (int32_t)c->psegs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+        const int cs = child_segment(c, seg, 0);
+        if (cs >= 0) {
+            int rc = cfmm_segment_info(c->shards[0], cs, kind, nullptr, block, grid, unroll);
+            if (rc != CFMM_OK) return rc;
+        }
+        if (kind) *kind = c->psegs[(size_t)seg].kind;
+        if (m) *m = c->psegs[(size_t)seg].m;
+        return CFMM_OK;
+    }
     if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
     int rc = ensure_geometry(const_cast<cfmm_ctx*>(c));
     if (rc != CFMM_OK) return rc;

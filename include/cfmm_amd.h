@@ -19,8 +19,8 @@
  *   - a cfmm_ctx is bound to one device and is not re-entrant; distinct contexts are
  *     independent.  Host-pointer calls are synchronous; *_dev calls are asynchronous on
  *     the context's stream.
- *   - pools are stored in SEGMENTS (one per cfmm_pools_add_* call, each homogeneous in
- *     pool family).  Trade arrays are laid out segment after segment in call order, so a
+ *   - pools are stored in SEGMENTS (one per cfmm_pools_add_* call with m > 0, each homogeneous
+ *     in pool family; an empty batch is accepted and ignored).  Trade arrays are laid out segment after segment in call order, so a
  *     router whose cfmms vector is grouped by family keeps the reference's pool order.
  */
 #ifndef CFMM_AMD_H
@@ -51,6 +51,24 @@ typedef struct cfmm_ctx cfmm_ctx;
 int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out);
 void cfmm_ctx_destroy(cfmm_ctx* ctx);
 
+/* The same Router sharded over the GPUs of one node from ONE host thread / process:
+ * the parallel axis of src/router.jl:39 (`Threads.@threads for i in 1:length(r.Δs)`) split into
+ * n_devices contiguous blocks.  Every cfmm_pools_add_* batch is divided into contiguous blocks over
+ * the devices (no pool is replicated); every host-pointer sweep (cfmm_find_arb, cfmm_eval, and
+ * therefore cfmm_route: ONE L-BFGS-B drives all shards) stages v on every device, runs the shard
+ * sweeps concurrently and adds the shards' {psi, acc} in device-list order on the host -- v comes
+ * from the host and psi returns to it on every evaluation, so the all-reduce of a sharded route! is
+ * n_devices * (n_tokens + 1) host additions; no peer mapping, no IPC, no RCCL, no torch.  Results
+ * are independent of the option "multi_threads" (1, default: one host worker thread per device
+ * launches and waits; 0: the calling thread launches on every device, then waits for each).
+ * A device id may be listed more than once (several shards on one GPU: used by the 1-GPU tests).
+ * Trade arrays keep the single-device layout (segment after segment, pools in upload order).
+ * Not available on such a context: cfmm_set_stream, cfmm_sweep_dev, cfmm_trades_dev, cfmm_set_peers
+ * (CFMM_ERR_UNSUPPORTED), and n_tokens > 8192.  For one process PER GPU use cfmm_ctx_create +
+ * cfmm_set_peers / RCCL instead (cfmmrouter.jl_amd/dist.py). */
+int cfmm_ctx_create_multi(int32_t n_devices, const int32_t* device_ids, int32_t n_tokens, cfmm_ctx** out);
+int32_t cfmm_device_count(const cfmm_ctx* ctx); /* shards of the context (1 for cfmm_ctx_create) */
+
 /* Message of the last failing call on ctx (ctx == NULL: last failing cfmm_ctx_create on
  * this thread).  Never NULL; valid until the next call on the same ctx/thread. */
 const char* cfmm_last_error(const cfmm_ctx* ctx);
@@ -64,8 +82,12 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
 
 /* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 512 | 1024 threads),
  * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
- * per block, 2 = one per wavefront), "time_kernels", "nt_stores", "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
- * walks only, 1 wavefront-cooperative deep walks), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream), "zero_copy" (default 1: host-pointer calls
+ * per block, 2 = one per wavefront), "time_kernels", "nt_stores" (trade stores: 0 plain, 1 non-temporal, 2 write-through = default), "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
+ * walks only, 1 wavefront-cooperative deep walks), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream),
+ * "host_flag" (default 1: a zero-copy host-pointer sweep ends when the last fold block raises a flag in mapped host memory,
+ * which the caller polls, instead of on the stream's completion signal), "inline_fold" (default 0; 1 = the partial rows are
+ * folded by extra blocks of the sweep launch instead of by a second launch -- same bits, measured slower), "multi_threads"
+ * (multi-device contexts, see cfmm_ctx_create_multi), "zero_copy" (default 1: host-pointer calls
  * exchange v / Psi through mapped pinned memory instead of copy commands), "fuse_segments" (default 1: all
  * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate
  * GeometricMeanTwoCoin with pow in the reference's operation order instead of the default

@@ -1,0 +1,124 @@
+"""Single-process multi-device context (cfmm_ctx_create_multi; SURVEY 8b/8e, the sharded axis of
+src/router.jl:39) on the 1-GPU box: the device list repeats ordinal 0, so N shards with N pool
+stores, N streams and N host worker threads run on one MI355X -- everything but the physical
+placement is what an 8-GPU node executes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from helpers import oracle_objective, oracle_poolset, oracle_sweep, rel_to_max
+from oracle import cfmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nd", [1, 2, 8])
+def test_plain_c_multi_client(tmp_path, nd):
+    exe = str(tmp_path / "abi_multi")
+    libdir = os.path.join(ROOT, "cfmmrouter.jl_amd")
+    subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_multi.c"), "-o", exe, "-L", libdir, "-lcfmm_amd",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
+    r = subprocess.run([exe, str(nd)] + ["0"] * nd, capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0
+    assert f"ok nd={nd}" in r.stdout and "two token indices must differ" in r.stdout
+
+
+@pytest.mark.parametrize("nd,threads", [(2, 1), (3, 0), (8, 1)])
+def test_mixed_families_sharded_equals_oracle(nd, threads):
+    n = 96
+    batches = [synth.product_pools(70_001, n, seed=1), synth.geomean_pools(30_000, n, seed=2),
+               synth.univ3_pools(9_000, n, 7, seed=3), synth.product_pools(5, n, seed=4)]   # 5 pools over 8 shards: empties
+    v = synth.sweep_prices(n, seed=9)
+    be = cr.DeviceBackend(n, batches, device=[0] * nd)
+    be.ctx.set_option("multi_threads", threads)
+    try:
+        assert be.ctx.device_count == nd and be.ctx.pool_count == sum(len(b) for b in batches)
+        psi, acc = be.find_arb(v)
+        D, L = be.trades()
+        Do, Lo, psi_o, acc_o = oracle_sweep(batches, n, v)
+        assert rel_to_max(psi, psi_o) <= 1e-12 and abs(acc - acc_o) <= 1e-12 * abs(acc_o)
+        g0, g1 = 70_001, 100_001
+        np.testing.assert_array_equal(D[:g0], Do[:g0])                 # ProductTwoCoin: bit-exact
+        np.testing.assert_array_equal(L[:g0], Lo[:g0])
+        np.testing.assert_array_equal(D[g1:], Do[g1:])                 # UniV3 (CSR rebased per shard) + the 5-pool batch
+        np.testing.assert_array_equal(L[g1:], Lo[g1:])
+        scale = np.maximum(batches[1].R.max(axis=1), 1.0)[:, None]
+        assert np.max(np.abs(D[g0:g1] - Do[g0:g1]) / scale) <= 1e-12   # GeometricMean: log-space forms
+        segs = be.ctx.segments()
+        assert [s["m"] for s in segs] == [len(b) for b in batches]
+        Dw, Lw = be.ctx.trades_range(2, 1000, 5000)
+        np.testing.assert_array_equal(Dw, Do[g1 + 1000:g1 + 6000])
+        psi2, acc2 = be.eval(v)                                        # fused evaluation: same bits
+        np.testing.assert_array_equal(psi2, psi)
+        assert acc2 == acc
+        with pytest.raises(RuntimeError):                              # eval does not produce trades
+            be.ctx.trades_range(2, 0, 1)
+    finally:
+        be.close()
+
+
+def test_config4_shape_eight_shards_route_parity():
+    """BASELINE config 4 in shape (ProductTwoCoin, 512 tokens, 8 shards), 1/10 of its size per shard so
+    that the oracle's route! stays in the test budget: ONE cfmm_route call drives all shards."""
+    n, m = 512, 400_000
+    batches = [synth.product_pools(m, n, seed=1234)]
+    obj = cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
+    r8 = cr.Router(obj, batches, n, device=[0] * 8)
+    r1 = cr.Router(obj, batches, n, device=0)
+    try:
+        cr.route_(r8, v=np.ones(n), solver="native")
+        cr.route_(r1, v=np.ones(n), solver="native")
+        ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(batches, n), v0=np.ones(n), nthreads=orc.lib().oracle_max_threads())
+        scale = np.max(np.abs(ref["psi"]))
+        assert np.max(np.abs(cr.netflows(r8) - ref["psi"])) <= 1e-6 * scale
+        assert np.max(np.abs(cr.netflows(r8) - cr.netflows(r1))) <= 1e-6 * scale
+        assert r8.info["funcalls"] >= 5
+        # trades at v*: the sharded router's equal a plain sweep of the whole market at the same v
+        D, L, _, _ = oracle_sweep(batches, n, r8.v, nthreads=orc.lib().oracle_max_threads())
+        np.testing.assert_array_equal(r8.Δs, D)
+        np.testing.assert_array_equal(r8.Λs, L)
+    finally:
+        r8.close()
+        r1.close()
+
+
+def test_failed_upload_rolls_back_every_shard():
+    """UniV3 batches are validated by the shards themselves: a bad pool in the LAST shard's block must
+    undo the blocks the earlier shards already stored."""
+    n = 16
+    good = synth.univ3_pools(4000, n, 5, seed=5)
+    be = cr.DeviceBackend(n, [good], device=[0, 0, 0, 0])
+    try:
+        bad = synth.univ3_pools(4000, n, 5, seed=6)
+        bad.liquidity[-2] = -1.0                      # last pool -> last shard
+        from cfmmrouter_amd.cfmms import _upload
+        with pytest.raises(cr.ArgumentError, match="shard 3"):
+            _upload(be.ctx, bad)
+        assert be.ctx.pool_count == 4000 and len(be.ctx.segments()) == 1
+        v = synth.sweep_prices(n, seed=7)
+        psi, acc = be.find_arb(v)
+        D, L, psi_o, acc_o = oracle_sweep([good], n, v)
+        assert rel_to_max(psi, psi_o) <= 1e-12
+        np.testing.assert_array_equal(be.trades()[0], D)
+    finally:
+        be.close()
+
+
+def test_multi_context_rejects_device_pointer_calls():
+    be = cr.DeviceBackend(8, [synth.product_pools(100, 8, seed=1)], device=[0, 0])
+    try:
+        with pytest.raises(NotImplementedError):
+            be.ctx.set_stream(0)
+        with pytest.raises(NotImplementedError):
+            be.ctx.sweep_dev(0x1000, 0x2000, False)
+        with pytest.raises(cr.ArgumentError):
+            cr.DeviceBackend(8, [], device=[0, 99])
+    finally:
+        be.close()
