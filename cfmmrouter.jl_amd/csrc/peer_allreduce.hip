@@ -13,9 +13,11 @@
 // seq+1 gather, which waited for every peer's seq+1 flag, i.e. for every peer to have finished
 // reading seq.  Peer data is read with system-scope atomic loads (L2-bypassing): the same
 // addresses were read two steps earlier and a cached copy would be stale.
-// Every spin is bounded; on timeout the output is poisoned with NaN so callers can detect it.
+// Every spin is bounded by wall-clock time (CFMM_AMD_PEER_TIMEOUT_S, default 30 s); on timeout the
+// output is poisoned with NaN, which cfmm_abi.hip (host_sweep_end) and dist.py check.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/cfmm_amd.h"
 
@@ -30,7 +32,7 @@ struct PeerArgs {
     long long count;
     unsigned long long seq;
     double* out;
-    long long spin_limit;
+    long long timeout_ticks;   // wall_clock64() ticks (100 MHz) a rank waits for a peer before it gives up
 };
 
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a)
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a)
         for (int p = 0; p < a.world; ++p) {
             if (base == 0) {   // wait once per peer
                 if (threadIdx.x == 0) {
-                    long long spins = 0;
+                    const long long t0 = (long long)wall_clock64();
                     while (__hip_atomic_load(a.flags[p] + parity, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
                         __builtin_amdgcn_s_sleep(2);
-                        if (++spins > a.spin_limit) { ok = 0; break; }
+                        if ((long long)wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }
                     }
                 }
                 __syncthreads();
@@ -88,7 +90,15 @@ extern "C" int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffer
     a.count = count;
     a.seq = seq;
     a.out = d_out;
-    a.spin_limit = 2000000; // ~ a second of s_sleep-paced polling, then give up (NaN output)
+    // Plain rank skew (a GC pause, a pool reload, a trade download on one rank) must not become a
+    // failure: wait up to CFMM_AMD_PEER_TIMEOUT_S seconds (default 30) of wall clock, then give up
+    // (NaN output, which every caller checks).
+    static const double timeout_s = [] {
+        const char* e = getenv("CFMM_AMD_PEER_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 30.0;
+    }();
+    a.timeout_ticks = (long long)(timeout_s * 1e8);
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
     return hipGetLastError() == hipSuccess ? CFMM_OK : CFMM_ERR_HIP;
 }

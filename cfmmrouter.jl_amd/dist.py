@@ -161,6 +161,9 @@ class ShardedBackend:
             self._out_pin.copy_(self._out, non_blocking=True)
             stream.synchronize()
         out = self._out_pin.numpy()
+        if not np.all(np.isfinite(out)):
+            raise RuntimeError("sharded sweep returned a non-finite {Ψ, acc}: a rank did not publish within the peer "
+                               "all-reduce's time limit (CFMM_AMD_PEER_TIMEOUT_S), or a shard overflowed")
         return out[:-1].copy(), float(out[-1])
 
     def eval(self, v):

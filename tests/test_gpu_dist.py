@@ -1,0 +1,61 @@
+"""The multi-process sharded paths on the MI355X at world = 1: RCCL process
+group + symmetric memory + cfmm_peer_allreduce + cfmm_set_peers, launched exactly as the driver
+launches bench.py (torch.distributed.run, 127.0.0.1 rendezvous).  The log is kept under
+gpurun_out/ and copied to profiles/ (r02_dist_world1.json)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_sharded_paths_world1_rccl_and_peer():
+    r = _torchrun([os.path.join(ROOT, "tests", "dist_world1_worker.py")])
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIST_WORLD1 ")][-1]
+    out = json.loads(line[len("DIST_WORLD1 "):])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dist_world1.json"), "w"), indent=1)
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["peer_available"] and out["peer_50_reduces_exact"]
+    assert out["peer"]["in_library_collective"] and not out["rccl"]["in_library_collective"]
+    for path in ("peer", "rccl"):
+        rec = out[path]
+        assert rec["fixed_v_netflow_equal"] and rec["trades_equal"]   # world 1: the all-reduce is the identity
+        assert rec["route_native_netflow_rel_diff"] <= 1e-9 and rec["route_scipy_netflow_rel_diff"] <= 1e-9
+        assert rec["route_native_evaluations"] >= 5
+
+
+@pytest.mark.parametrize("extra", [[], ["--rccl"]])
+def test_bench_under_torchrun_world1(extra):
+    """bench.py exactly as the driver launches it for N > 1, at N = 1: RCCL init, the collective in the
+    timed step, the self-check against a plain all-reduce, the sharded route! leg."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+                   "--workload", "config4shard"] + extra)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["collective_check_rel_err"] <= 1e-12
+    assert ("RCCL" in line["config"]["sharding"]) == bool(extra)
+    rs = line["route_sharded"]
+    assert "error" not in rs and rs["ranks_agree_on_v"] and rs["evaluations"] >= 5
+    tag = "rccl" if extra else "peer"
+    json.dump(line, open(os.path.join(ROOT, "gpurun_out", f"bench_torchrun_world1_{tag}.json"), "w"), indent=1)
