@@ -196,19 +196,46 @@ def main():
     v_t = torch.from_numpy(v).to("cuda")
     out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
     materialize = not args.fused
-    peer = None
+    # N > 1 (or N = 1 under torchrun): the launch that folds the partial rows also all-reduces {Ψ, acc}
+    # over xGMI peer mappings (cfmm_set_peers: one launch, rank-ordered sum, bit-identical on every
+    # rank).  At start-up that path is checked against sweep + RCCL all-reduce on every rank; if it is
+    # unavailable or disagrees anywhere, ALL ranks use the RCCL all-reduce instead.
+    peer, fused_peer, peer_ptrs, n_fused = None, False, None, 0
     if use_dist and not args.rccl and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
         from cfmmrouter_amd.dist import PeerAllReduce
         peer = PeerAllReduce.create(n + 1, None, torch.device("cuda", local_rank))  # None -> RCCL fallback
+        if peer is not None:
+            peer_ptrs = [int(p) for p in peer.hdl.buffer_ptrs]
+            good = True
+            for _ in range(3):
+                be.ctx.set_peers(peer_ptrs, world, rank, n_fused)
+                be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+                n_fused += 1
+                got = out_t.clone()
+                be.ctx.set_peers([], 0, 0, 0)
+                be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+                ref = out_t.clone()
+                dist.all_reduce(ref)
+                torch.cuda.synchronize()
+                good = good and bool(torch.isfinite(got).all()) and \
+                    float((got - ref).abs().max()) <= 1e-12 * float(ref.abs().max())
+            flag = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            fused_peer = float(flag.item()) == 1.0
+            if fused_peer:
+                be.ctx.set_peers(peer_ptrs, world, rank, n_fused)
 
     def step():
-        if peer is not None:   # fold into the symmetric slot, then the one-shot xGMI gather (rank-ordered sum)
-            be.ctx.sweep_dev(v_t.data_ptr(), peer.slot().data_ptr(), materialize)
-            peer.reduce(out_t)
-        else:
-            be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
-            if use_dist:
-                dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
+        be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)   # sharded context: already the global {Ψ, acc}
+        if use_dist and not fused_peer:
+            dist.all_reduce(out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
+
+    n_steps_run = [0]
+    _plain_step = step
+
+    def step():   # noqa: F811 -- counts the fused sweeps so that the sequence can be resumed after a local sweep
+        _plain_step()
+        n_steps_run[0] += 1
 
     for _ in range(args.warmup):
         step()
@@ -224,9 +251,10 @@ def main():
             step()
         ev1.record(stream)
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+        dt = time.perf_counter() - t0   # this rank's K steps are complete (with the collective inside every step no
+        if use_dist:                    # rank finishes step k before all ranks contributed to it); the closing
+            dist.barrier()              # barrier follows the clock read, and the MAX over ranks is reported
+        return dt, ev0.elapsed_time(ev1)
 
     # pass 1 -- THE timed region: K steps between barrier+synchronize, nothing else on the stream
     elapsed, dev_ms = timed_pass()
@@ -282,10 +310,14 @@ def main():
     if use_dist:
         step()
         got = out_t.clone()
+        if fused_peer:
+            be.ctx.set_peers([], 0, 0, 0)           # a LOCAL sweep for the reference
         be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
         ref = out_t.clone()
         dist.all_reduce(ref)
         torch.cuda.synchronize()
+        if fused_peer:
+            be.ctx.set_peers(peer_ptrs, world, rank, n_fused + n_steps_run[0])
         collective_check = float((got - ref).abs().max() / ref.abs().max())
 
     # sharded route!: every rank drives the same L-BFGS-B on the all-reduced {Ψ, acc} of its own shard
@@ -388,8 +420,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
                    "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
-                   "sharding": ((f"pools x{world}, one-shot xGMI peer all-reduce of n_tokens+1 f64 per step"
-                                 if peer is not None else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
+                   "sharding": ((f"pools x{world}, fold + one-shot xGMI peer all-reduce of n_tokens+1 f64 in one launch per step"
+                                 if fused_peer else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
                                 if use_dist else "single GPU, no collective")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -120,6 +120,7 @@ struct cfmm_ctx {
     std::vector<uint64_t> peers;  // device addresses of all ranks' symmetric buffers
     int peer_rank = 0;
     uint64_t peer_seq = 0;
+    long long peer_timeout_ticks = 3000000000ll;   // 30 s of wall_clock64() at 100 MHz (CFMM_AMD_PEER_TIMEOUT_S)
     double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out, then one uint64 completion flag
     double* d_stage = nullptr;    // device address of h_stage
     unsigned* d_sync = nullptr;   // [kSyncWords] arrival counters of the in-launch fold (zero between launches)
@@ -418,10 +419,11 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool timed = c->opt_time_kernels != 0 && c->pending.size() < (1u << 20); // harvest with cfmm_kernel_times
     const bool gb = global_bins(c);
     // One launch per evaluation: the partial rows are folded by extra blocks of that launch.
-    const bool inline_fold = c->opt_inline_fold != 0 && !gb && c->groups.size() == 1 && c->rows_total > 0 &&
+    const bool sharded = !c->peers.empty();   // fold + all-reduce over the peer mappings in one launch
+    const bool inline_fold = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
                              c->n <= kMaxFoldTokens && c->d_sync != nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
-    const bool flagged = want_host_flag && !gb && c->rows_total > 0 && c->d_sync != nullptr;
+    const bool flagged = want_host_flag && !gb && !sharded && c->rows_total > 0 && c->d_sync != nullptr;
     c->last_inline = inline_fold;
     c->last_flagged = flagged;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -496,10 +498,23 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         ra = take_event(c);
         rb = take_event(c);
         if (!ra || !rb) ra = rb = nullptr;
-        if (ra && !inline_fold && (gb || c->rows_total == 0)) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
+        if (ra && !inline_fold && (gb || (c->rows_total == 0 && !sharded))) HIP_TRY(c, hipEventRecord(ra, c->stream)); // several launches: bracket them
     }
     if (inline_fold) {
         // nothing to launch: the sweep launch has already produced d_out
+    } else if (sharded) {
+        PeerSet ps;
+        const int64_t count = c->n + 1;
+        for (size_t p = 0; p < c->peers.size(); ++p)
+            ps.gran[p] = reinterpret_cast<unsigned long long*>(c->peers[p] + (uint64_t)(2 * count + 2) * sizeof(double));
+        ps.world = (int)c->peers.size();
+        ps.rank = c->peer_rank;
+        ps.count = count;
+        ps.seq = ++c->peer_seq;
+        ps.timeout_ticks = c->peer_timeout_ticks;
+        hipError_t e = launch_reduce_gather(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream,
+                                            c->groups.empty() ? kSmallBlock : c->groups.back().block, ps, ra, rb);
+        if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "fold + gather launch failed: %s", hipGetErrorString(e));
     } else if (c->rows_total > 0) {
         hipError_t e;
         if (gb) { // pull Ψ per token over the incidence list, then fold the dual-scalar column
@@ -515,7 +530,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)(c->n + 1) * sizeof(double), c->stream));
     }
     if (ra && rb && !inline_fold) {
-        if (gb || c->rows_total == 0) HIP_TRY(c, hipEventRecord(rb, c->stream));
+        if (gb || (c->rows_total == 0 && !sharded)) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
     if (materialize) c->have_trades = true;
@@ -547,15 +562,7 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
     }
     // {Ψ, acc}: the last kernel of the evaluation writes into the mapped pinned buffer when it can
     double* out_dst = zero_copy ? c->d_stage + c->n : c->d_out;
-    if (!c->peers.empty()) {
-        // sharded: fold into this rank's symmetric slot, then the one-shot gather over xGMI
-        const uint64_t seq = ++c->peer_seq;
-        double* slot = reinterpret_cast<double*>(c->peers[(size_t)c->peer_rank]) + (seq & 1ull) * (uint64_t)(c->n + 1);
-        int rc = enqueue_sweep(c, v_src, slot, materialize);
-        if (rc != CFMM_OK) return rc;
-        rc = cfmm_peer_allreduce(c->stream, c->peers.data(), (int32_t)c->peers.size(), c->peer_rank, c->n + 1, seq, out_dst);
-        if (rc != CFMM_OK) return fail(c, rc, "cfmm_peer_allreduce launch failed");
-    } else {
+    {   // sharded contexts (cfmm_set_peers): the fold launch also gathers the peers' {Ψ, acc} over xGMI
         int rc = enqueue_sweep(c, v_src, out_dst, materialize, zero_copy && c->opt_host_flag != 0);
         if (rc != CFMM_OK) return rc;
     }
@@ -1348,6 +1355,10 @@ int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int
     c->peers.assign(peer_buffers, peer_buffers + world);
     c->peer_rank = rank;
     c->peer_seq = seq;
+    if (const char* e = getenv("CFMM_AMD_PEER_TIMEOUT_S")) {
+        const double t = atof(e);
+        if (t > 0.0) c->peer_timeout_ticks = (long long)(t * 1e8);
+    }
     return CFMM_OK;
 }
 

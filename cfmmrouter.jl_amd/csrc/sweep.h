@@ -126,6 +126,22 @@ hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, 
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, unsigned* sync = nullptr,
                          unsigned long long* host_flag = nullptr, unsigned long long host_seq = 0);
 
+// Sharded runs (cfmm_set_peers): the row fold fused with the one-shot all-reduce over xGMI peer
+// mappings (reduce_gather in sweep_kernels.hip): block b folds its kReduceCols columns, publishes
+// them as self-validating granules in this rank's symmetric buffer and adds the same columns of
+// every peer in rank order -- one launch instead of reduce_partials + cfmm_peer_allreduce, one hop
+// on the critical path, no hand-off between the blocks of a rank.
+constexpr int kMaxPeers = 16;
+struct PeerSet {
+    unsigned long long* gran[kMaxPeers];    // peer p's granules: [2][count][2] uint64 (see include/cfmm_amd.h)
+    int world, rank;
+    long long count;                        // n_tokens + 1
+    unsigned long long seq;                 // 1, 2, ... identical on every rank
+    long long timeout_ticks;                // wall_clock64() ticks (100 MHz) before a wait gives up (NaN output)
+};
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
+                                const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 size_t sweep_lds_bytes(int n_pad, int copies, int block);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 

@@ -756,6 +756,62 @@ __global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restric
     fold_finish(tsum, true, n1, out, sync, (int)gridDim.x, false, host_flag, host_seq);
 }
 
+// Fold + all-reduce in one launch (sharded runs, see sweep.h).  The exchange uses self-validating
+// 8-byte granules {tag = sequence number, 32 bits of payload} (MI355X_MICROARCH.md, hand-off form R2:
+// "the data IS the flag"): each column travels as two granules (low / high half of the double), each
+// written by ONE aligned 8-byte system-scope store, so there is no separate flag, no store drain and
+// no second hop -- a reader simply re-reads a peer's granules (system-scope loads, which bypass the
+// caches) until both carry this evaluation's tag.  This rank's own columns never leave registers.
+// Double buffering by sequence parity: a rank rewrites gran[parity] for seq+2 only after its seq+1
+// launch, which waited for every peer's seq+1 granules, i.e. for every peer's seq launch -- the one
+// that read gran[parity] -- to have completed.  Waits are bounded by wall-clock time (NaN output).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict__ partials, int rows, int n1,
+                                                       double* __restrict__ out, PeerSet ps)
+{
+    __shared__ double red[(BLOCK / 64) * kReduceCols];
+    const double tsum = fold_columns<BLOCK, false>(partials, rows, n1, blockIdx.x, red);
+    const int tid = threadIdx.x;
+    if (tid >= 64) return;                                // the exchange is wavefront 0's business
+    const int parity = (int)(ps.seq & 1ull);
+    const unsigned long long tag = (ps.seq % 0xffffffffull + 1ull) << 32;   // never 0 (= an empty buffer)
+    const int col = blockIdx.x * kReduceCols + tid;
+    if (tid < kReduceCols && col < n1 && ps.world > 1) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(tsum);
+        unsigned long long* g = ps.gran[ps.rank] + 2 * ((long long)parity * ps.count + col);
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // lane = (peer slot q, column c): 8 peers x 8 columns per pass, two passes cover kMaxPeers = 16
+    const int q = tid / kReduceCols, c = tid % kReduceCols;
+    const int colc = blockIdx.x * kReduceCols + c;
+    const double own = __shfl(tsum, c, 64);
+    double x[2] = {0.0, 0.0};
+    bool ok = true;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = q + 8 * pass;
+        if (p >= ps.world || colc >= n1) continue;
+        if (p == ps.rank) { x[pass] = own; continue; }
+        const unsigned long long* g = ps.gran[p] + 2 * ((long long)parity * ps.count + colc);
+        const long long t0 = (long long)wall_clock64();
+        for (;;) {
+            const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((a & 0xffffffff00000000ull) == tag && (b & 0xffffffff00000000ull) == tag) {
+                x[pass] = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+                break;
+            }
+            if ((long long)wall_clock64() - t0 > ps.timeout_ticks) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    ok = __all(ok);
+    double s = 0.0;                                       // rank order on every rank: bit-identical results
+    for (int p = 0; p < ps.world; ++p) s += __shfl(p < 8 ? x[0] : x[1], (p & 7) * kReduceCols + c, 64);
+    if (tid < kReduceCols && col < n1) out[col] = ok ? s : __builtin_nan("");
+}
+
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat
 // indices 2·pool + side of the flows that belong to the token; it is cut into chunks of at most
 // kGatherChunk entries so that hub tokens (a numeraire with 10⁵ pools) are spread over many
@@ -957,6 +1013,16 @@ hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, 
         launch_k(&reduce_partials<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
     else
         launch_k(&reduce_partials<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
+                                const PeerSet& ps, hipEvent_t e0, hipEvent_t e1)
+{
+    dim3 g((n1 + kReduceCols - 1) / kReduceCols);
+    if (block == kBigBlock) launch_k(&reduce_gather<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
+    else if (block == kMidBlock) launch_k(&reduce_gather<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
+    else launch_k(&reduce_gather<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
     return hipGetLastError();
 }
 

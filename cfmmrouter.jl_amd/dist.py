@@ -42,7 +42,8 @@ class PeerAllReduce:
         self._torch, self._C, self._lib = torch, C, lib()
         self.count = int(count)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        words = 2 * self.count + 2                       # [2][count] doubles + 2 uint64 flags
+        # [2][count] doubles + 2 uint64 flags (this class's kernel) + [2][count][2] granules (cfmm_set_peers)
+        words = 6 * self.count + 2
         self.buf = symm_mem.empty(words, dtype=torch.float64, device=device)
         self.buf.zero_()
         gname = (group or dist.group.WORLD).group_name
@@ -111,7 +112,9 @@ def shard_batches(batches, rank: int, world: int):
 
 
 class ShardedBackend:
-    """A rank-local backend plus the per-evaluation all-reduce of {Ψ, acc}."""
+    """A rank-local backend plus the per-evaluation all-reduce of {Ψ, acc} through torch.distributed
+    (RCCL on GPUs, gloo in the CPU tests) -- the fall-back of ShardedRouter; its fast path keeps the
+    collective inside the library (cfmm_set_peers: the fold launch gathers over xGMI)."""
 
     def __init__(self, local, group=None):
         import torch
@@ -130,11 +133,6 @@ class ShardedBackend:
             self._out_pin = torch.empty(self.n_tokens + 1, dtype=torch.float64).pin_memory()
             self._dev = dev
             self._stream = torch.cuda.Stream(device=dev)   # sweep, all-reduce and copies share it
-            self._peer = None
-            import os
-            if dist.get_backend(group) == "nccl" and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
-                with torch.cuda.device(dev), torch.cuda.stream(self._stream):
-                    self._peer = PeerAllReduce.create(self.n_tokens + 1, group, dev)
 
     def _reduce_host(self, psi, acc):
         t = self._torch.from_numpy(np.concatenate([psi, [acc]]))
@@ -152,12 +150,8 @@ class ShardedBackend:
             self.local.ctx.set_stream(stream.cuda_stream)
             self._v_pin.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)))
             self._v.copy_(self._v_pin, non_blocking=True)
-            if self._peer is not None:      # fold straight into the symmetric slot, one-shot gather over xGMI
-                self.local.ctx.sweep_dev(self._v.data_ptr(), self._peer.slot().data_ptr(), materialize)
-                self._peer.reduce(self._out)
-            else:
-                self.local.ctx.sweep_dev(self._v.data_ptr(), self._out.data_ptr(), materialize)
-                self._dist.all_reduce(self._out, group=self.group)   # RCCL, 8·(n_tokens+1) bytes
+            self.local.ctx.sweep_dev(self._v.data_ptr(), self._out.data_ptr(), materialize)
+            self._dist.all_reduce(self._out, group=self.group)   # RCCL, 8·(n_tokens+1) bytes
             self._out_pin.copy_(self._out, non_blocking=True)
             stream.synchronize()
         out = self._out_pin.numpy()
@@ -211,7 +205,7 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
             with torch.cuda.device(dev):
                 peer = PeerAllReduce.create(n_tokens + 1, group, torch.device("cuda", dev))
             if peer is not None:
-                backend.ctx.set_peers([int(p) for p in peer.hdl.buffer_ptrs], world, rank, peer.seq)
+                backend.ctx.set_peers([int(p) for p in peer.hdl.buffer_ptrs], world, rank, 0)   # the granules are fresh
                 backend.peer = peer   # keeps the symmetric allocation alive
                 return Router(objective, local, n_tokens, _backend=backend)
     return Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))

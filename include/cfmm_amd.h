@@ -165,23 +165,32 @@ int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
 
 /* One-shot all-reduce(sum) of `count` doubles across the `world` GPUs of one node.  peer_buffers[p]
  * is the device address, mapped into THIS process, of rank p's symmetric buffer laid out as
- * [2][count] doubles followed by 2 uint64 flags, zero-initialised before first use (e.g. a
- * torch.distributed._symmetric_memory allocation: hdl.buffer_ptrs).  Before the call, this rank's
+ * [2][count] doubles followed by 2 uint64 flags (+ the granules of cfmm_set_peers, unused here),
+ * zero-initialised before first use (e.g. a torch.distributed._symmetric_memory allocation:
+ * hdl.buffer_ptrs).  Before the call, this rank's
  * contribution must have been written (on the same stream) to its own buffer at
  * [seq & 1][0..count) -- cfmm_sweep_dev can target it directly.  seq starts at 1 and increases by
  * one per call on every rank.  Every rank sums the peers in rank order, so all ranks obtain
- * bit-identical results.  Asynchronous on hip_stream; if a peer does not publish within about a
- * second the output is filled with NaN instead of hanging.  Replaces nothing in the reference
+ * bit-identical results.  Asynchronous on hip_stream; if a peer does not publish within
+ * CFMM_AMD_PEER_TIMEOUT_S seconds (default 30) the output is filled with NaN instead of hanging.  Replaces nothing in the reference
  * (it has no distributed path); it is the collective of SURVEY 8e. */
 int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t world, int32_t rank,
                         int64_t count, uint64_t seq, double* d_out);
 
-/* Sharded operation of a context: after this call every host-pointer sweep (cfmm_find_arb,
- * cfmm_eval, and therefore cfmm_route) ends with cfmm_peer_allreduce over the given symmetric
- * buffers ([2][n_tokens+1] doubles + 2 uint64 flags each, see above), so psi / acc / route results
- * are those of the WHOLE market while the context stores only this rank's shard.  Every rank must
- * issue the same sequence of sweeps (route! does: all ranks take bit-identical L-BFGS-B steps).
- * seq = number of all-reduces already performed on these buffers.  world = 0 switches it off. */
+/* Sharded operation of a context (one process per GPU): after this call EVERY sweep of the context --
+ * cfmm_find_arb, cfmm_eval, cfmm_route, and cfmm_sweep_dev -- returns the psi / acc of the WHOLE
+ * market while the context stores only this rank's shard: the launch that folds the partial rows
+ * also performs the all-reduce over the given symmetric buffers (block b publishes its columns as
+ * self-validating 8-byte granules {sequence tag, 32 payload bits} in this rank's buffer -- no flag, no
+ * fence -- and adds the same columns of every peer in rank order: every rank obtains bit-identical
+ * results).  Buffer layout, per rank, with count = n_tokens + 1, zero-initialised before first use:
+ *     [2][count] doubles | 2 uint64 (data + flags of cfmm_peer_allreduce) | [2][count][2] uint64 granules
+ * i.e. (6 * count + 2) 8-byte words (e.g. a torch.distributed._symmetric_memory allocation;
+ * peer_buffers[p] = address of rank p's buffer mapped into THIS process).  Every rank
+ * must issue the same sequence of sweeps (route! does: all ranks take bit-identical L-BFGS-B steps).
+ * seq = number of sharded sweeps already performed on these buffers (0 for fresh ones).  A rank
+ * waits up to CFMM_AMD_PEER_TIMEOUT_S seconds (environment, default 30) for a peer, then the output
+ * is NaN and host-pointer calls fail with CFMM_ERR_STATE.  world = 0 switches sharding off. */
 int cfmm_set_peers(cfmm_ctx* ctx, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq);
 
 /* ---- route! without an interpreter in the loop ----------------------- */
