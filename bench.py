@@ -64,8 +64,13 @@ WORKLOADS = {
                               synth.geomean_pools(500_000, 256, seed=1234, first=rank * 500_000)]),
     "config4shard": ("500k ProductTwoCoin pools per GPU (4M over 8 GPUs), 512 tokens", 512,
                      lambda rank: [synth.product_pools(500_000, 512, seed=1234, first=rank * 500_000)]),
-    "config5": ("1M BoundedProduct (2-tick UniV3) pools, 256 tokens, BasketLiquidation", 256,
-                lambda rank: [synth.bounded_product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
+    "config5": ("1M BoundedProduct (2-tick UniV3) pools quoted around one token price vector (1 % noise), 256 tokens, "
+                "BasketLiquidation (interior dual optimum)", 256,
+                lambda rank: [synth.bounded_product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000,
+                                                          consistent=True)]),
+    "config5corner": ("1M BoundedProduct pools with independent random prices (arbitrage-rich: route! ends at the box "
+                      "corner after 2 evaluations), 256 tokens, BasketLiquidation", 256,
+                      lambda rank: [synth.bounded_product_pools(1_000_000, 256, seed=1234, first=rank * 1_000_000)]),
     "large_n": ("1M ProductTwoCoin pools, 65536 tokens (global-bin path), LinearNonnegative arbitrage", 65536,
                 lambda rank: [synth.product_pools(1_000_000, 65536, seed=1234, first=rank * 1_000_000)]),
     "product1m": ("1M ProductTwoCoin pools, 256 tokens, LinearNonnegative arbitrage", 256,
@@ -74,7 +79,7 @@ WORKLOADS = {
 
 
 def objective_for(name, n):
-    if name == "config5":
+    if name.startswith("config5"):
         return cr.BasketLiquidation(1, synth.basket(n, seed=1234))
     return cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
 

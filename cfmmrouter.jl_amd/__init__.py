@@ -6,7 +6,7 @@ through libcfmm_amd.so (include/cfmm_amd.h); there is no CPU fallback in this pa
 """
 from ._lib import ArgumentError, CFMMDeviceError, Context, build, lib
 from .cfmms import (CFMM, BoundedProduct, GeometricMeanTwoCoin, PoolBatch, ProductTwoCoin, UniV3, find_arb_ as _find_arb_pool,
-                    zerotrade)
+                    grad_phi_, phi, zerotrade, ϕ, ϕ_grad_)
 from .objectives import (BasketLiquidation, LinearNonnegative, Objective, Swap, f, grad_, lower_limit,
                          upper_limit)
 from .router import DeviceBackend, Router, find_arb_ as _find_arb_router, netflows, netflows_, route_, update_reserves_
@@ -23,5 +23,5 @@ __all__ = [
     "CFMM", "ProductTwoCoin", "GeometricMeanTwoCoin", "UniV3", "BoundedProduct", "PoolBatch", "find_arb_",
     "update_reserves_", "Objective", "LinearNonnegative", "BasketLiquidation", "Swap", "f", "grad_",
     "lower_limit", "upper_limit", "Router", "route_", "netflows_", "netflows", "ArgumentError",
-    "CFMMDeviceError", "Context", "DeviceBackend", "build", "lib", "zerotrade",
+    "CFMMDeviceError", "Context", "DeviceBackend", "build", "lib", "zerotrade", "ϕ", "ϕ_grad_", "phi", "grad_phi_",
 ]

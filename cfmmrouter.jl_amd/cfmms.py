@@ -79,6 +79,40 @@ class GeometricMeanTwoCoin(CFMM):
         return PoolBatch(KIND_GEOMEAN, R=R, w=w, γ=γ, Ai=idx)
 
 
+def ϕ(cfmm, R=None):
+    """ϕ(c::CFMM; R=nothing): the trading function -- src/cfmms.jl:36-42, :113-116 (ProductTwoCoin:
+    R₁R₂), :167-171 (GeometricMeanTwoCoin: R₁^w₁ R₂^w₂).  The reference defines no method for UniV3.
+    Host-side definition (O(1) per pool, used by the optimality tests, not by the sweep)."""
+    if not isinstance(cfmm, (ProductTwoCoin, GeometricMeanTwoCoin)):
+        raise ArgumentError("ϕ has no method for this pool type (as in the reference)")
+    R = cfmm.R if R is None else np.asarray(R, dtype=np.float64)
+    if isinstance(cfmm, ProductTwoCoin):
+        return R[0] * R[1]
+    if isinstance(cfmm, GeometricMeanTwoCoin):
+        return R[0] ** cfmm.w[0] * R[1] ** cfmm.w[1]
+    raise ArgumentError("ϕ has no method for this pool type (as in the reference)")
+
+
+def ϕ_grad_(out, cfmm, R=None):
+    """∇ϕ!(x, c::CFMM; R=nothing): gradient of the trading function, stored in `out` --
+    src/cfmms.jl:44-50, :117-122, :172-178."""
+    if not isinstance(cfmm, (ProductTwoCoin, GeometricMeanTwoCoin)):
+        raise ArgumentError("∇ϕ! has no method for this pool type (as in the reference)")
+    R = cfmm.R if R is None else np.asarray(R, dtype=np.float64)
+    if isinstance(cfmm, ProductTwoCoin):
+        out[0], out[1] = R[1], R[0]
+        return None
+    if isinstance(cfmm, GeometricMeanTwoCoin):
+        w = cfmm.w
+        out[0] = w[0] * (R[1] / R[0]) ** w[1]
+        out[1] = w[1] * (R[0] / R[1]) ** w[0]
+        return None
+    raise ArgumentError("∇ϕ! has no method for this pool type (as in the reference)")
+
+
+phi, grad_phi_ = ϕ, ϕ_grad_   # ASCII spellings ("∇" is not a valid Python identifier character, hence ϕ_grad_ for ∇ϕ!)
+
+
 class UniV3(CFMM):
     """UniV3(current_price, lower_ticks, liquidity, γ, Ai) -- src/cfmms.jl:206-245.
 

@@ -64,13 +64,28 @@ def geomean_pools(m, n_tokens, seed=1234, first=0):
     return PoolBatch(KIND_GEOMEAN, R=R, w=w, γ=γ, Ai=token_pairs(seed, 23, m, n_tokens, first))
 
 
-def bounded_product_pools(m, n_tokens, seed=1234, first=0):
+def token_price_vector(n_tokens, seed=1234):
+    """The common price vector π behind `bounded_product_pools(..., consistent=True)`: exp(U[-1,1))."""
+    return np.exp(2.0 * uniform(seed, 36, n_tokens) - 1.0)
+
+
+def bounded_product_pools(m, n_tokens, seed=1234, first=0, consistent=False, noise=0.01):
     """m stand-alone BoundedProduct pools as 2-tick UniV3 (second tick empty), config 5.
 
     The reference gives no distribution for these (only the hand fixture test/cfmms.jl:117-119);
-    this generator's choice: current price p ~ exp(U[-1,1)), price band [p/(1+a), p(1+b)] with
-    a, b ~ U[0.05, 0.55), liquidity (the squared invariant k) ~ 1e6·U[0.01,1)."""
-    p = np.exp(2.0 * uniform(seed, 30, m, first) - 1.0)
+    this generator's choice: price band [p/(1+a), p(1+b)] around the current price p with
+    a, b ~ U[0.05, 0.55), liquidity (the squared invariant k) ~ 1e6·U[0.01,1), and
+      * consistent=False: p ~ exp(U[-1,1)) independently per pool -- an arbitrage-rich market whose dual
+        optimum sits on the box corner (route! ends after 2 evaluations);
+      * consistent=True: p = π[i₁]/π[i₂]·exp(noise·U[-1,1)) for one token price vector π
+        (`token_price_vector`), i.e. a market close to no-arbitrage as real pools are, in which a
+        BasketLiquidation has an INTERIOR dual optimum and route! has to find π (tens of evaluations)."""
+    Ai = token_pairs(seed, 35, m, n_tokens, first)
+    if consistent:
+        π = token_price_vector(n_tokens, seed)
+        p = π[Ai[:, 0] - 1] / π[Ai[:, 1] - 1] * np.exp(noise * (2.0 * uniform(seed, 30, m, first) - 1.0))
+    else:
+        p = np.exp(2.0 * uniform(seed, 30, m, first) - 1.0)
     a = 0.05 + 0.5 * uniform(seed, 31, m, first)
     b = 0.05 + 0.5 * uniform(seed, 32, m, first)
     k = 1e6 * (0.01 + 0.99 * uniform(seed, 33, m, first))
@@ -79,7 +94,7 @@ def bounded_product_pools(m, n_tokens, seed=1234, first=0):
     liquidity = np.stack([k, np.zeros(m)], axis=1).reshape(-1)
     tick_off = 2 * np.arange(m + 1, dtype=np.int64)
     return PoolBatch(KIND_UNIV3, current_price=p, tick_off=tick_off, lower_ticks=lower_ticks,
-                     liquidity=liquidity, γ=γ, Ai=token_pairs(seed, 35, m, n_tokens, first))
+                     liquidity=liquidity, γ=γ, Ai=Ai)
 
 
 def univ3_pools(m, n_tokens, ticks_per_pool, seed=1234, first=0):

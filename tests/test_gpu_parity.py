@@ -452,6 +452,47 @@ def test_route_named_config_shapes(shape, solver):
     r.close()
 
 
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+def test_route_config5_interior_optimum(solver):
+    """BASELINE config 5 on a market that is close to no-arbitrage (BoundedProduct pools quoted around
+    one token price vector, 1 % noise): the BasketLiquidation dual has an INTERIOR optimum, route! has
+    to discover the price vector from v = 1/n, and L-BFGS-B runs for tens of evaluations (on the
+    arbitrage-rich random market it stops after 2, at the box corner).  300k pools, 256 tokens."""
+    n, m = 256, 300_000
+    market = [synth.bounded_product_pools(m, n, seed=1234, consistent=True)]
+    obj = cr.BasketLiquidation(1, synth.basket(n, seed=1234))
+    r = cr.Router(obj, market, n)
+    cr.route_(r, solver=solver)
+    ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(market, n), v0=None, nthreads=_threads())
+    assert r.info["funcalls"] >= 10 and ref["info"]["funcalls"] >= 10
+    # Both runs stop on factr = 1e1 (relative decrease of the dual <= 10 eps) with a stationarity residual
+    # max_i |Ψ_i + Δin_i| of ~1e-6 max|Ψ| left: that residual, not the sweep, bounds how well two runs of the
+    # SAME algorithm agree on Ψ (the CPU restatement alone moves by 1e-6 max|Ψ| when v0 is perturbed by 1e-16,
+    # profiles/r02_route_scatter.txt).  Asserted: the same dual value to 1e-12, and Ψ equal to within
+    # north_star's 1e-6 plus the two residuals.
+    Ψ, scale = cr.netflows(r), np.max(np.abs(ref["psi"]))
+    res_dev = np.max(np.abs(Ψ[1:] + obj.Δin[1:])) / scale
+    res_ref = np.max(np.abs(ref["psi"][1:] + obj.Δin[1:])) / scale
+    assert res_dev <= 1e-5 and res_ref <= 1e-5
+    assert np.max(np.abs(Ψ[1:] - ref["psi"][1:])) / scale <= ROUTE_TOL + 2 * (res_dev + res_ref)
+    assert abs(r.info["f"] - ref["f"]) <= 1e-12 * max(1.0, abs(ref["f"]))
+    # Ψ[0], the amount of the output token received, is the PRIMAL objective; its price sits on its bound, so
+    # no stationarity condition pins it and it inherits the residuals amplified by the dual's curvature
+    # (observed: 3.6e-6).  It is certified instead by the duality gap: primal value == dual value to 1e-5.
+    assert abs(Ψ[0] - r.info["f"]) <= 1e-5 * abs(r.info["f"]) and abs(ref["psi"][0] - ref["f"]) <= 1e-5 * abs(ref["f"])
+    assert abs(Ψ[0] - ref["psi"][0]) <= 1e-5 * scale
+    lo = cr.lower_limit(obj)
+    assert np.all(r.v[1:] > lo[1:] * 1e3)                 # interior: only the output token's price sits on its bound ...
+    π = synth.token_price_vector(n, seed=1234)
+    assert np.std(np.log(r.v / π)) < 0.02                 # ... and v* is the market's price vector up to scale
+    assert Ψ[0] > 0 and np.all(Ψ[1:] + obj.Δin[1:] >= -1e-5 * scale)
+    # trades at v*: every row equals a plain oracle sweep at the same prices
+    Do, Lo, _, _ = oracle_sweep(market, n, r.v, nthreads=_threads())
+    np.testing.assert_array_equal(r.Δs, Do)
+    np.testing.assert_array_equal(r.Λs, Lo)
+    r.close()
+
+
 @pytest.mark.parametrize("kind", ["arb", "basket", "mixed"])
 def test_route_native_solver_one_call(kind):
     """cfmm_route: the whole of route! inside the library (own L-BFGS-B) vs the CPU restatement."""
@@ -496,10 +537,31 @@ def test_no_fee_optimality_after_update_reserves(solver):
     r.close()
 
 
-# ---- BASELINE-size properties (no oracle at this size inside the timed budget) ---------------------------
+# ---- BASELINE sizes: EVERY row against the threaded oracle (it sweeps 1M pools in well under a second) ----
 
-def test_full_size_properties():
-    """1M ProductTwoCoin pools, 256 tokens: size-independent checks."""
+NT = None
+
+
+def _threads():
+    global NT
+    if NT is None:
+        NT = max(1, int(orc.lib().oracle_max_threads()))
+    return NT
+
+
+def _size_independent_checks(b_list, D, L, psi, acc, v, n):
+    """Properties that hold at any size: feasibility, one direction per pool, the device's Ψ / dual
+    scalar are the sums of its own trades, no pool trades at a loss."""
+    assert np.all(D >= 0) and np.all(L >= 0)
+    assert not np.any((D[:, 0] > 0) & (D[:, 1] > 0)) and not np.any((L[:, 0] > 0) & (L[:, 1] > 0))
+    Ai0 = np.concatenate([b.Ai for b in b_list]).astype(np.int32) - 1
+    assert rel_to_max(psi, orc.netflows(D, L, Ai0, n)) <= REDUCE_TOL
+    profit = (L * v[Ai0]).sum(1) - (D * v[Ai0]).sum(1)
+    assert np.all(profit >= -1e-9) and abs(profit.sum() - acc) <= 1e-9 * abs(acc)
+
+
+def test_full_size_product1m_all_rows():
+    """1M ProductTwoCoin pools, 256 tokens (the north_star's ProductTwoCoin instance): all rows bit-exact."""
     m, n = 1_000_000, 256
     b = synth.product_pools(m, n, seed=1234)
     v = synth.sweep_prices(n, seed=1234)
@@ -507,58 +569,127 @@ def test_full_size_properties():
     psi, acc = be.find_arb(v)
     D, L = be.trades()
     be.close()
-    assert np.all(D >= 0) and np.all(L >= 0)
-    assert not np.any((D[:, 0] > 0) & (D[:, 1] > 0))                  # one direction per pool
+    Do, Lo, psi_o, acc_o = oracle_sweep([b], n, v, nthreads=_threads())
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psi_o) <= REDUCE_TOL and abs(acc - acc_o) <= REDUCE_TOL * abs(acc_o)
+    _size_independent_checks([b], D, L, psi, acc, v, n)
     Rn = b.R + b.γ[:, None] * D - L
-    k0, k1 = b.R[:, 0] * b.R[:, 1], Rn[:, 0] * Rn[:, 1]
-    assert np.all(k1 >= k0 * (1 - 1e-12))                             # trading function not decreased
-    Ai0 = (b.Ai - 1).astype(np.int32)
-    psi_host = orc.netflows(D, L, Ai0, n)                             # checksum of the device's own trades
-    assert rel_to_max(psi, psi_host) <= REDUCE_TOL
-    i = np.arange(0, m, 997)                                          # spot-check rows against the oracle
-    Do, Lo = orc.sweep_product(b.R[i], b.γ[i], Ai0[i], v)
-    np.testing.assert_array_equal(D[i], Do)
-    np.testing.assert_array_equal(L[i], Lo)
+    assert np.all(Rn[:, 0] * Rn[:, 1] >= b.R[:, 0] * b.R[:, 1] * (1 - 1e-12))   # trading function not decreased
 
 
-def test_full_size_properties_config3_and_config5():
-    """BASELINE configs 3 and 5 at full size: size-independent properties + oracle spot rows."""
-    n = 256
+def test_full_size_config3_all_rows():
+    """BASELINE config 3 at full size (500k ProductTwoCoin + 500k GeometricMeanTwoCoin, 256 tokens)."""
+    n, h = 256, 500_000
     v = synth.sweep_prices(n, seed=1234)
-    # config 3: 500k ProductTwoCoin + 500k GeometricMeanTwoCoin
-    bp, bg = synth.product_pools(500_000, n, seed=1234), synth.geomean_pools(500_000, n, seed=1234)
+    bp, bg = synth.product_pools(h, n, seed=1234), synth.geomean_pools(h, n, seed=1234)
     be = cr.DeviceBackend(n, [bp, bg])
     psi, acc = be.find_arb(v)
     D, L = be.trades()
+    psi_f, acc_f = be.eval(v)                                           # the fused evaluation route! uses
     be.close()
-    assert np.all(D >= 0) and np.all(L >= 0) and not np.any((D[:, 0] > 0) & (D[:, 1] > 0))
-    Rn = bg.R + bg.γ[:, None] * D[500_000:] - L[500_000:]
+    Do, Lo, psi_o, acc_o = oracle_sweep([bp, bg], n, v, nthreads=_threads())
+    np.testing.assert_array_equal(D[:h], Do[:h])                       # ProductTwoCoin half: bit-exact
+    np.testing.assert_array_equal(L[:h], Lo[:h])
+    scale = np.maximum(bg.R.max(axis=1), 1.0)[:, None]                 # GeometricMean half: log-space forms,
+    assert np.max(np.abs(D[h:] - Do[h:]) / scale) <= GEOM_RTOL         # <= 1e-12 of the reserve scale, every row
+    assert np.max(np.abs(L[h:] - Lo[h:]) / scale) <= GEOM_RTOL
+    assert np.array_equal(D[h:] > 0, Do[h:] > 0) and np.array_equal(L[h:] > 0, Lo[h:] > 0)   # same pools trade
+    assert rel_to_max(psi, psi_o) <= REDUCE_TOL and abs(acc - acc_o) <= REDUCE_TOL * abs(acc_o)
+    np.testing.assert_array_equal(psi_f, psi)
+    assert acc_f == acc
+    _size_independent_checks([bp, bg], D, L, psi, acc, v, n)
+    Rn = bg.R + bg.γ[:, None] * D[h:] - L[h:]
     phi0 = bg.w[:, 0] * np.log(bg.R[:, 0]) + bg.w[:, 1] * np.log(bg.R[:, 1])
     phi1 = bg.w[:, 0] * np.log(Rn[:, 0]) + bg.w[:, 1] * np.log(Rn[:, 1])
-    assert np.all(phi1 >= phi0 - 1e-11)                     # weighted invariant not decreased
-    Ai0 = np.concatenate([bp.Ai, bg.Ai]).astype(np.int32) - 1
-    assert rel_to_max(psi, orc.netflows(D, L, Ai0, n)) <= REDUCE_TOL
-    profit = (L * v[Ai0]).sum(1) - (D * v[Ai0]).sum(1)
-    assert np.all(profit >= -1e-9) and abs(profit.sum() - acc) <= 1e-9 * acc   # every pool's arbitrage pays; dual scalar
-    i = np.arange(0, 500_000, 991)
-    Dg, Lg = orc.sweep_geomean(bg.R[i], bg.w[i], bg.γ[i], (bg.Ai[i] - 1).astype(np.int32), v)
-    assert np.max(np.abs(D[500_000 + i] - Dg)) <= 1e-9 and np.max(np.abs(L[500_000 + i] - Lg)) <= 1e-9
-    # config 5: 1M BoundedProduct pools (2-tick UniV3)
+    assert np.all(phi1 >= phi0 - 1e-11)                                # weighted invariant not decreased
+
+
+def test_full_size_config4_shard_all_rows():
+    """One GPU's share of BASELINE config 4: 500k ProductTwoCoin pools, 512 tokens."""
+    m, n = 500_000, 512
+    b = synth.product_pools(m, n, seed=1234)
+    v = synth.sweep_prices(n, seed=1234)
+    be = cr.DeviceBackend(n, [b])
+    psi, acc = be.find_arb(v)
+    D, L = be.trades()
+    be.close()
+    Do, Lo, psi_o, acc_o = oracle_sweep([b], n, v, nthreads=_threads())
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psi_o) <= REDUCE_TOL and abs(acc - acc_o) <= REDUCE_TOL * abs(acc_o)
+    _size_independent_checks([b], D, L, psi, acc, v, n)
+
+
+def test_full_size_config5_all_rows():
+    """BASELINE config 5 at full size: 1M BoundedProduct pools (2-tick UniV3), all rows bit-exact."""
+    n = 256
+    v = synth.sweep_prices(n, seed=1234)
     bu = synth.bounded_product_pools(1_000_000, n, seed=1234)
     be = cr.DeviceBackend(n, [bu])
     psi, acc = be.find_arb(v)
     D, L = be.trades()
     be.close()
-    assert np.all(D >= 0) and np.all(L >= 0) and not np.any((D[:, 0] > 0) & (D[:, 1] > 0))
-    Au = (bu.Ai - 1).astype(np.int32)
-    assert rel_to_max(psi, orc.netflows(D, L, Au, n)) <= REDUCE_TOL
-    i = np.arange(0, 1_000_000, 997)
-    sub = bu.slice(0, 1_000_000)
-    ct = orc.univ3_current_ticks(bu.current_price[i], 2 * np.arange(len(i) + 1), bu.lower_ticks.reshape(-1, 2)[i].reshape(-1))
-    Du, Lu = orc.sweep_univ3(bu.current_price[i], ct, bu.γ[i], Au[i], 2 * np.arange(len(i) + 1),
-                             bu.lower_ticks.reshape(-1, 2)[i].reshape(-1), bu.liquidity.reshape(-1, 2)[i].reshape(-1), v)
-    np.testing.assert_array_equal(D[i], Du)
-    np.testing.assert_array_equal(L[i], Lu)
+    Do, Lo, psi_o, acc_o = oracle_sweep([bu], n, v, nthreads=_threads())
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psi_o) <= REDUCE_TOL and abs(acc - acc_o) <= REDUCE_TOL * abs(acc_o)
+    _size_independent_checks([bu], D, L, psi, acc, v, n)
+
+
+# ---- the reference's optimality predicate (test/cfmms.jl:3-22) on DEVICE trades ---------------------
+
+SQRT_EPS = math.sqrt(np.finfo(float).eps)
+
+
+def _isapprox(a, b):   # Julia's isapprox with its default rtol = sqrt(eps)
+    return abs(a - b) <= SQRT_EPS * max(abs(a), abs(b))
+
+
+def _optimality_conditions_met(c, Δ, Λ, cfmm):
+    """test_optimality_conditions_met(c, Δ, Λ, cfmm) -- test/cfmms.jl:3-22, with the host mirror's ϕ / ∇ϕ!"""
+    R, γ = cfmm.R, cfmm.γ
+    Rp = R + γ * Δ - Λ
+    pfeas = np.all(Δ >= 0) and np.all(Λ >= 0)
+    ϕR, ϕRp = cr.ϕ(cfmm), cr.ϕ(cfmm, R=Rp)
+    g = np.zeros(2)
+    cr.ϕ_grad_(g, cfmm, R=Rp)
+    cfmm_sat = _isapprox(ϕR, ϕRp) and ϕRp >= ϕR - SQRT_EPS
+    opt = max(γ * g[i] / c[i] for i in range(2)) <= min(g[i] / c[i] for i in range(2)) + SQRT_EPS
+    return pfeas and cfmm_sat and opt
+
+
+def test_reference_optimality_predicate_on_device_trades():
+    """test/cfmms.jl:63-67, :92-96 (product) and :100-107 (geo mean): 3 reserves x 3 fees x 3 price
+    vectors (x 3 weights), find_arb! on the MI355X, the reference's predicate on what comes back."""
+    rng = np.random.default_rng(1234)
+    γs, Rs, νs = rng.random(3), rng.random((3, 2)) * 10, rng.random((3, 2))
+    ws = [np.array([w1, 1 - w1]) for w1 in rng.random(3)]
+    Δ, Λ = np.zeros(2), np.zeros(2)
+    for R in Rs:
+        for γ in γs:
+            for ν in νs:
+                cfmm = cr.ProductTwoCoin(R, γ, [1, 2])
+                cr.find_arb_(Δ, Λ, cfmm, ν)
+                assert _optimality_conditions_met(ν, Δ, Λ, cfmm)
+                for w in ws:
+                    cfmm = cr.GeometricMeanTwoCoin(R, w, γ, [1, 2])
+                    cr.find_arb_(Δ, Λ, cfmm, ν)
+                    assert _optimality_conditions_met(ν, Δ, Λ, cfmm)
+
+
+def test_reference_optimality_predicate_on_a_swept_market():
+    """The same predicate on every pool of a 20k-pool mixed sweep (batch path, fused launch)."""
+    n = 32
+    bp, bg = synth.product_pools(10_000, n, seed=77), synth.geomean_pools(10_000, n, seed=78)
+    v = synth.sweep_prices(n, seed=79, spread=0.5)
+    be = cr.DeviceBackend(n, [bp, bg])
+    be.find_arb(v)
+    D, L = be.trades()
+    be.close()
+    for k in range(0, 10_000, 7):
+        assert _optimality_conditions_met(v[bp.Ai[k] - 1], D[k], L[k], bp[k])
+        assert _optimality_conditions_met(v[bg.Ai[k] - 1], D[10_000 + k], L[10_000 + k], bg[k])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CFMM_FUZZ_SEEDS", "12"))))

@@ -56,6 +56,23 @@ class TestConstructors:
         g = cr.GeometricMeanTwoCoin([1, 2], [0.3, 0.7], 1, [2, 1])
         assert list(g.Ai) == [2, 1] and g.w[1] == 0.7
 
+    def test_trading_functions_match_oracle(self):  # src/cfmms.jl:113-122, :167-178
+        rng = np.random.default_rng(3)
+        for _ in range(20):
+            R, w1 = rng.random(2) * 100 + 0.1, rng.uniform(0.05, 0.95)
+            p = cr.ProductTwoCoin(R, 0.997, [1, 2])
+            g = cr.GeometricMeanTwoCoin(R, [w1, 1 - w1], 0.997, [1, 2])
+            R2 = rng.random(2) * 50 + 0.1
+            out = np.zeros(2)
+            assert cr.ϕ(p) == orc.product_phi(R) and cr.ϕ(p, R=R2) == orc.product_phi(R2)
+            cr.ϕ_grad_(out, p, R=R2)
+            np.testing.assert_array_equal(out, orc.product_grad_phi(R2))
+            assert abs(cr.ϕ(g, R=R2) - orc.geomean_phi(R2, g.w)) <= 1e-14 * orc.geomean_phi(R2, g.w)
+            cr.ϕ_grad_(out, g, R=R2)
+            np.testing.assert_allclose(out, orc.geomean_grad_phi(R2, g.w), rtol=1e-14)
+        with pytest.raises(cr.ArgumentError):
+            cr.ϕ(cr.UniV3(15.0, [30., 20, 10, 5], [1.0, 2.0, 1.5, 0.0], 1.0, [1, 2]))
+
     def test_univ3_current_tick(self):  # src/cfmms.jl:235
         for cp, ct in [(15.0, 2), (20.0, 2), (30.0, 1), (31.0, 0), (1.0, 4)]:
             assert cr.UniV3(cp, [30., 20, 10, 5], [1.0, 2.0, 1.5, 0.0], 1.0, [1, 2]).current_tick == ct
