@@ -109,6 +109,9 @@ def lib():
     L.cfmm_get_trades_range.argtypes = [_ctx, C.c_int32, C.c_int64, C.c_int64, _f64p, _f64p]
     L.cfmm_netflows.argtypes = [_ctx, _f64p]
     L.cfmm_dual_value.argtypes = [_ctx, _f64p]
+    L.cfmm_update_reserves.argtypes = [_ctx]
+    L.cfmm_get_reserves.argtypes = [_ctx, C.c_int32, _f64p]
+    L.cfmm_get_prices.argtypes = [_ctx, C.c_int32, _f64p]
     L.cfmm_sweep_dev.argtypes = [_ctx, C.c_void_p, C.c_void_p, C.c_int]
     L.cfmm_trades_dev.argtypes = [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.cfmm_kernel_times.argtypes = [_ctx, _i64p, _f64p, _i64p, _f64p]
@@ -296,6 +299,20 @@ class Context:
                                        int(m), float(factr), float(pgtol), int(maxfun), int(maxiter), ptr(v),
                                        ptr(psi), C.byref(info)))
         return v, psi, info.as_dict()
+
+    def update_reserves(self):
+        """update_reserves!(r) on the device (cfmm_update_reserves): consumes the latest materialised trades."""
+        self._check(self._L.cfmm_update_reserves(self._h))
+
+    def reserves(self, seg: int, m: int):
+        R = np.empty((int(m), 2))
+        self._check(self._L.cfmm_get_reserves(self._h, int(seg), ptr(R)))
+        return R
+
+    def prices(self, seg: int, m: int):
+        p = np.empty(int(m))
+        self._check(self._L.cfmm_get_prices(self._h, int(seg), ptr(p)))
+        return p
 
     def set_peers(self, peer_ptrs, world: int, rank: int, seq: int):
         """Sharded operation: every host-pointer sweep of this context ends with the one-shot peer

@@ -57,7 +57,10 @@ struct Segment {
     int grid = 0;
     int unroll = 1;
     int64_t row_off = 0; // first partial row
-    std::vector<int32_t> h_ai; // host copy of Ai, kept only in large-market mode (incidence build)
+    std::vector<int32_t> h_ai; // host copy of Ai: large-market mode (incidence build) and UniV3 segments
+    // UniV3 only: the pool definitions as uploaded (update_reserves! moves current_price and re-derives the constants)
+    std::vector<double> h_cp, h_gamma, h_lt, h_liq;
+    std::vector<int64_t> h_tick_off;
 };
 
 // A launch: either one segment (sweep_kernel) or up to kMaxMulti segments fused (sweep_multi).
@@ -128,6 +131,7 @@ struct cfmm_ctx {
     bool last_inline = false;     // the latest enqueue_sweep folded inside the sweep launch
     bool last_flagged = false;    // ... and raises the host flag (the caller may poll it instead of the stream)
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
+    std::vector<double> trade_v;  // v of the latest MATERIALISING host-pointer sweep (empty: none / device-pointer sweep)
     bool have_out = false;
     bool have_trades = false;
     bool geometry_dirty = true;
@@ -551,6 +555,7 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
+    if (materialize) c->trade_v.assign(v, v + c->n);   // the prices the device trades belong to (update_reserves!)
     double* h_out = c->h_stage + c->n;
     const bool zero_copy = c->opt_zero_copy != 0 && c->d_stage != nullptr;
     // v: small vectors are read by every block straight from the mapped pinned buffer (the PCIe
@@ -792,6 +797,121 @@ int add_segment_common(cfmm_ctx* c, Segment&& s, const int32_t* Ai)
     c->have_out = false;
     c->have_trades = false;
     return CFMM_OK;
+}
+
+// Validates m UniV3 pools and prepares + uploads the find_arb_pos constants (see UniV3Ops) into `s`.
+int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price, const double* gamma, const int32_t* Ai,
+                const int64_t* tick_off, const double* lower_ticks, const double* liquidity)
+{
+    const int64_t T = m > 0 ? tick_off[m] : 0;
+    if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
+    std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
+    std::vector<double> rout, cur_c((size_t)m);
+    std::vector<int4> walk((size_t)m);
+    int longest = 0;
+    ks.reserve((size_t)T + (size_t)m);
+    dt.reserve((size_t)T + (size_t)m);
+    rout.reserve((size_t)T + (size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
+        if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
+        if (!finite_pos(current_price[i]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: current_price must be finite and > 0", (long long)i);
+        if (!finite_pos(gamma[i]))
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: fee gamma must be finite and > 0", (long long)i);
+        const int32_t a = Ai[2 * i], b = Ai[2 * i + 1];
+        if (a < 0 || a >= c->n || b < 0 || b >= c->n)
+            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: token index out of range [0, %d)", (long long)i, c->n);
+        if (a == b) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: the two token indices must differ", (long long)i);
+        const double* lt = lower_ticks + o;
+        const double* lq = liquidity + o;
+        for (int64_t j = 0; j < nt; ++j) {
+            if (!finite_pos(lt[j])) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: price must be finite and > 0", (long long)i, (long long)j);
+            if (j > 0 && !(lt[j] < lt[j - 1]))
+                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: lower_ticks must be strictly descending", (long long)i);
+            if (!(lq[j] >= 0.0) || !std::isfinite(lq[j]))
+                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: liquidity must be finite and >= 0", (long long)i, (long long)j);
+        }
+        const double cp = current_price[i];
+        // src/cfmms.jl:235: searchsortedlast(lower_ticks, current_price, rev=true)
+        int64_t lo = 0, hi = nt + 1;
+        while (lo < hi - 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (lt[mid - 1] < cp) hi = mid;
+            else lo = mid;
+        }
+        const int64_t ct = lo;
+        if (ct < 1)
+            return fail(c, CFMM_ERR_INVALID_ARG,
+                        "pool %lld: current_price above the first tick (the reference would index tick 0)", (long long)i);
+        // compute_at_tick(cfmm, idx), src/cfmms.jl:294-313 (idx 1-based)
+        auto at_tick = [&](int64_t idx, double& k, double& al, double& be, double& R1, double& R2) {
+            k = lq[idx - 1];
+            const double pplus = lt[idx - 1];                 // :251
+            const double pminus = idx < nt ? lt[idx] : 0.0;   // :254-259
+            al = std::sqrt(k / pplus);
+            be = std::sqrt(k * pminus);
+            const double p = idx > ct ? pplus : (idx < ct ? pminus : cp);
+            R1 = std::sqrt(k / p) - al;
+            R2 = std::sqrt(k * p) - be;
+        };
+        {   // the current tick, shared by both walks
+            double k, al, be, R1, R2;
+            at_tick(ct, k, al, be, R1, R2);
+            const double sA = R1 + al, sB = R2 + be;
+            cur_a[(size_t)i] = make_double2(k, sA);
+            cur_b[(size_t)i] = make_double2(sB, k / be - sA);   // :329
+            cur_c[(size_t)i] = k / al - sB;                     // :329 on the flipped pool (:289)
+            curR[(size_t)i] = make_double2(R1, R2);
+            if (k == 0) { cur_b[(size_t)i].y = 0.0; cur_c[(size_t)i] = 0.0; } // 0/0: never read (k == 0 is skipped)
+        }
+        int4 w;
+        w.x = (int)ks.size();
+        int cnt = 0;
+        for (int64_t idx = ct + 1; idx <= nt; ++idx) {        // get_upper_pools beyond the current tick, :316
+            double k, al, be, R1, R2;
+            at_tick(idx, k, al, be, R1, R2);
+            if (k == 0) continue;                             // is_empty_pool, :288
+            const double s_in = R1 + al;
+            ks.push_back(make_double2(k, s_in));
+            dt.push_back(make_double2(k / be - s_in, R2 + be)); // :329, :334
+            rout.push_back(R2);
+            ++cnt;
+        }
+        w.y = cnt;
+        w.z = (int)ks.size();
+        cnt = 0;
+        for (int64_t idx = ct - 1; idx >= 1; --idx) {         // flip_sides.(get_lower_pools), :317,:289
+            double k, al, be, R1, R2;
+            at_tick(idx, k, al, be, R1, R2);
+            if (k == 0) continue;
+            const double s_in = R2 + be;
+            ks.push_back(make_double2(k, s_in));
+            dt.push_back(make_double2(k / al - s_in, R1 + al));
+            rout.push_back(R1);
+            ++cnt;
+        }
+        w.w = cnt;
+        longest = std::max(longest, std::max(w.y, w.w));
+        walk[(size_t)i] = w;
+        pg[(size_t)i] = make_double2(cp, gamma[i]);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    s.kind = CFMM_KIND_UNIV3;
+    s.m = m;
+    s.n_ticks_total = T;
+    s.deep = longest > 8 ? 1 : 0; // short ladders: a lane walks its own pool; long: the wavefront helps
+    int rc;
+    if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
+        (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
+        (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
+        (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
+        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size()))) {
+        free_segment(s);
+        return rc;
+    }
+    return CFMM_OK;
+
 }
 
 } // namespace
@@ -1068,114 +1188,16 @@ int cfmm_pools_add_univ3(cfmm_ctx* c, int64_t m, const double* current_price, co
                                         lower_ticks + tick_off[lo], liquidity + tick_off[lo]);
         });
     }
-    const int64_t T = m > 0 ? tick_off[m] : 0;
-    if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
-    std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
-    std::vector<double> rout, cur_c((size_t)m);
-    std::vector<int4> walk((size_t)m);
-    int longest = 0;
-    ks.reserve((size_t)T + (size_t)m);
-    dt.reserve((size_t)T + (size_t)m);
-    rout.reserve((size_t)T + (size_t)m);
-    for (int64_t i = 0; i < m; ++i) {
-        const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
-        if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
-        if (!finite_pos(current_price[i]))
-            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: current_price must be finite and > 0", (long long)i);
-        if (!finite_pos(gamma[i]))
-            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: fee gamma must be finite and > 0", (long long)i);
-        const int32_t a = Ai[2 * i], b = Ai[2 * i + 1];
-        if (a < 0 || a >= c->n || b < 0 || b >= c->n)
-            return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: token index out of range [0, %d)", (long long)i, c->n);
-        if (a == b) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: the two token indices must differ", (long long)i);
-        const double* lt = lower_ticks + o;
-        const double* lq = liquidity + o;
-        for (int64_t j = 0; j < nt; ++j) {
-            if (!finite_pos(lt[j])) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: price must be finite and > 0", (long long)i, (long long)j);
-            if (j > 0 && !(lt[j] < lt[j - 1]))
-                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: lower_ticks must be strictly descending", (long long)i);
-            if (!(lq[j] >= 0.0) || !std::isfinite(lq[j]))
-                return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld tick %lld: liquidity must be finite and >= 0", (long long)i, (long long)j);
-        }
-        const double cp = current_price[i];
-        // src/cfmms.jl:235: searchsortedlast(lower_ticks, current_price, rev=true)
-        int64_t lo = 0, hi = nt + 1;
-        while (lo < hi - 1) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if (lt[mid - 1] < cp) hi = mid;
-            else lo = mid;
-        }
-        const int64_t ct = lo;
-        if (ct < 1)
-            return fail(c, CFMM_ERR_INVALID_ARG,
-                        "pool %lld: current_price above the first tick (the reference would index tick 0)", (long long)i);
-        // compute_at_tick(cfmm, idx), src/cfmms.jl:294-313 (idx 1-based)
-        auto at_tick = [&](int64_t idx, double& k, double& al, double& be, double& R1, double& R2) {
-            k = lq[idx - 1];
-            const double pplus = lt[idx - 1];                 // :251
-            const double pminus = idx < nt ? lt[idx] : 0.0;   // :254-259
-            al = std::sqrt(k / pplus);
-            be = std::sqrt(k * pminus);
-            const double p = idx > ct ? pplus : (idx < ct ? pminus : cp);
-            R1 = std::sqrt(k / p) - al;
-            R2 = std::sqrt(k * p) - be;
-        };
-        {   // the current tick, shared by both walks
-            double k, al, be, R1, R2;
-            at_tick(ct, k, al, be, R1, R2);
-            const double sA = R1 + al, sB = R2 + be;
-            cur_a[(size_t)i] = make_double2(k, sA);
-            cur_b[(size_t)i] = make_double2(sB, k / be - sA);   // :329
-            cur_c[(size_t)i] = k / al - sB;                     // :329 on the flipped pool (:289)
-            curR[(size_t)i] = make_double2(R1, R2);
-            if (k == 0) { cur_b[(size_t)i].y = 0.0; cur_c[(size_t)i] = 0.0; } // 0/0: never read (k == 0 is skipped)
-        }
-        int4 w;
-        w.x = (int)ks.size();
-        int cnt = 0;
-        for (int64_t idx = ct + 1; idx <= nt; ++idx) {        // get_upper_pools beyond the current tick, :316
-            double k, al, be, R1, R2;
-            at_tick(idx, k, al, be, R1, R2);
-            if (k == 0) continue;                             // is_empty_pool, :288
-            const double s_in = R1 + al;
-            ks.push_back(make_double2(k, s_in));
-            dt.push_back(make_double2(k / be - s_in, R2 + be)); // :329, :334
-            rout.push_back(R2);
-            ++cnt;
-        }
-        w.y = cnt;
-        w.z = (int)ks.size();
-        cnt = 0;
-        for (int64_t idx = ct - 1; idx >= 1; --idx) {         // flip_sides.(get_lower_pools), :317,:289
-            double k, al, be, R1, R2;
-            at_tick(idx, k, al, be, R1, R2);
-            if (k == 0) continue;
-            const double s_in = R2 + be;
-            ks.push_back(make_double2(k, s_in));
-            dt.push_back(make_double2(k / al - s_in, R1 + al));
-            rout.push_back(R1);
-            ++cnt;
-        }
-        w.w = cnt;
-        longest = std::max(longest, std::max(w.y, w.w));
-        walk[(size_t)i] = w;
-        pg[(size_t)i] = make_double2(cp, gamma[i]);
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
-    s.kind = CFMM_KIND_UNIV3;
-    s.m = m;
-    s.n_ticks_total = T;
-    s.deep = longest > 8 ? 1 : 0; // short ladders: a lane walks its own pool; long: the wavefront helps
-    int rc;
-    if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
-        (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
-        (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
-        (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
-        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size()))) {
-        free_segment(s);
-        return rc;
-    }
+    int rcb = univ3_build(c, s, m, current_price, gamma, Ai, tick_off, lower_ticks, liquidity);
+    if (rcb != CFMM_OK) return rcb;
+    // host copy of the pool definitions: update_reserves! re-derives the tick constants from them
+    s.h_cp.assign(current_price, current_price + m);
+    s.h_gamma.assign(gamma, gamma + m);
+    s.h_ai.assign(Ai, Ai + 2 * m);
+    s.h_tick_off.assign(tick_off, tick_off + m + 1);
+    s.h_lt.assign(lower_ticks, lower_ticks + tick_off[m]);
+    s.h_liq.assign(liquidity, liquidity + tick_off[m]);
     return add_segment_common(c, std::move(s), Ai);
 }
 
@@ -1283,11 +1305,119 @@ int cfmm_dual_value(cfmm_ctx* c, double* acc)
     return CFMM_OK;
 }
 
+int cfmm_update_reserves(cfmm_ctx* c)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {
+        if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb / cfmm_route first");
+        for (size_t d = 0; d < c->shards.size(); ++d) {
+            cfmm_ctx* child = c->shards[d];
+            if (child->segs.empty()) continue;
+            const int rc = cfmm_update_reserves(child);
+            if (rc != CFMM_OK) return fail(c, rc, "shard %d: %s", (int)d, child->err.c_str());
+        }
+        c->have_trades = c->have_out = false;
+        return CFMM_OK;
+    }
+    if (!c->have_trades) return fail(c, CFMM_ERR_STATE, "no materialised trades: call cfmm_find_arb / cfmm_route first");
+    bool any_univ3 = false;
+    for (const Segment& s : c->segs) any_univ3 = any_univ3 || s.kind == CFMM_KIND_UNIV3;
+    if (any_univ3 && (int)c->trade_v.size() != c->n)
+        return fail(c, CFMM_ERR_STATE, "UniV3 pools need the prices of the trades: run the materialising sweep through "
+                                       "cfmm_find_arb / cfmm_route (host pointer), not cfmm_sweep_dev");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (Segment& s : c->segs) {
+        if (s.kind != CFMM_KIND_UNIV3) {   // R <- R + γΔ − Λ on the device, no host traffic
+            hipError_t e = launch_update_two_coin(s.R, s.gamma, c->d_delta + s.trade_off, c->d_lambda + s.trade_off,
+                                                  s.kind == CFMM_KIND_GEOMEAN ? s.lR : nullptr, s.m, c->stream);
+            if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "update launch failed: %s", hipGetErrorString(e));
+            continue;
+        }
+        // UniV3: the pool's state is its price.  find_arb! (src/cfmms.jl:339-395) moves a trading pool to
+        // the internal price P = p/γ (price falling, :361) or γ·p (price rising, :381 in the flipped
+        // frame), p = v₁/v₂ -- through every fully drained tick and part of the last one -- and leaves a
+        // pool inside its no-arbitrage band (:347-349) alone.  P above the first tick means the pool ran
+        // out of liquidity on that side and rests at the first tick's upper price.  Tick constants are
+        // then re-derived exactly as at upload (compute_at_tick, :294-313).
+        const double* v = c->trade_v.data();
+        std::vector<double> cp(s.h_cp);
+        for (int64_t i = 0; i < s.m; ++i) {
+            const double g = s.h_gamma[(size_t)i], q = s.h_cp[(size_t)i];
+            const double pr = v[s.h_ai[(size_t)(2 * i)]] / v[s.h_ai[(size_t)(2 * i + 1)]];   // :340
+            if (g * q <= pr && pr <= q / g) continue;                                        // :347-349
+            double P = pr < g * q ? pr / g : g * pr;
+            const double top = s.h_lt[(size_t)s.h_tick_off[(size_t)i]];
+            cp[(size_t)i] = P > top ? top : P;
+        }
+        Segment ns;
+        const int rc = univ3_build(c, ns, s.m, cp.data(), s.h_gamma.data(), s.h_ai.data(), s.h_tick_off.data(),
+                                   s.h_lt.data(), s.h_liq.data());
+        if (rc != CFMM_OK) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // nothing in flight still reads the old constants
+        (void)hipFree(s.pg); (void)hipFree(s.Ai); (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c);
+        (void)hipFree(s.curR); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
+        s.pg = ns.pg; s.Ai = ns.Ai; s.cur_a = ns.cur_a; s.cur_b = ns.cur_b; s.cur_c = ns.cur_c; s.curR = ns.curR;
+        s.walk = ns.walk; s.ks = ns.ks; s.dt = ns.dt; s.rout = ns.rout; s.deep = ns.deep;
+        s.h_cp.swap(cp);
+    }
+    c->have_trades = false;   // consumed: the trades no longer describe an arbitrage of the stored pools
+    c->have_out = false;
+    c->trade_v.clear();
+    return CFMM_OK;
+}
+
+int cfmm_get_reserves(cfmm_ctx* c, int32_t seg, double* R)
+{
+    if (!c || !R) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {
+        if (seg < 0 || seg >= (int32_t)c->psegs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+        const int nd = (int)c->shards.size();
+        for (int d = 0; d < nd; ++d) {
+            int64_t lo, hi;
+            shard_range(c->psegs[(size_t)seg].m, d, nd, lo, hi);
+            if (hi == lo) continue;
+            const int rc = cfmm_get_reserves(c->shards[(size_t)d], child_segment(c, seg, d), R + 2 * lo);
+            if (rc != CFMM_OK) return fail(c, rc, "shard %d: %s", d, c->shards[(size_t)d]->err.c_str());
+        }
+        return CFMM_OK;
+    }
+    if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+    const Segment& s = c->segs[(size_t)seg];
+    if (s.kind == CFMM_KIND_UNIV3) return fail(c, CFMM_ERR_INVALID_ARG, "UniV3 segments have prices, not reserves: cfmm_get_prices");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(R, s.R, (size_t)s.m * sizeof(double2), hipMemcpyDeviceToHost));
+    return CFMM_OK;
+}
+
+int cfmm_get_prices(cfmm_ctx* c, int32_t seg, double* current_price)
+{
+    if (!c || !current_price) return CFMM_ERR_INVALID_ARG;
+    if (!c->shards.empty()) {
+        if (seg < 0 || seg >= (int32_t)c->psegs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+        const int nd = (int)c->shards.size();
+        for (int d = 0; d < nd; ++d) {
+            int64_t lo, hi;
+            shard_range(c->psegs[(size_t)seg].m, d, nd, lo, hi);
+            if (hi == lo) continue;
+            const int rc = cfmm_get_prices(c->shards[(size_t)d], child_segment(c, seg, d), current_price + lo);
+            if (rc != CFMM_OK) return fail(c, rc, "shard %d: %s", d, c->shards[(size_t)d]->err.c_str());
+        }
+        return CFMM_OK;
+    }
+    if (seg < 0 || seg >= (int32_t)c->segs.size()) return fail(c, CFMM_ERR_INVALID_ARG, "segment out of range");
+    const Segment& s = c->segs[(size_t)seg];
+    if (s.kind != CFMM_KIND_UNIV3) return fail(c, CFMM_ERR_INVALID_ARG, "not a UniV3 segment: cfmm_get_reserves");
+    std::copy(s.h_cp.begin(), s.h_cp.end(), current_price);
+    return CFMM_OK;
+}
+
 int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materialize)
 {
     if (!c || !d_v || !d_out) return CFMM_ERR_INVALID_ARG;
     CFMM_SINGLE_ONLY(c, "cfmm_sweep_dev");
     c->have_out = false; // results live on the device; the host copy is stale
+    if (materialize) c->trade_v.clear();   // the library has not seen these prices
     return enqueue_sweep(c, d_v, d_out, materialize != 0);
 }
 

@@ -142,6 +142,10 @@ struct PeerSet {
 hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                                 const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// R <- (R + gamma*Delta) - Lambda in place; lR (nullable) <- {log R1, log R2}
+hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
+                                  double2* lR, int64_t m, hipStream_t s);
+
 size_t sweep_lds_bytes(int n_pad, int copies, int block);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 

@@ -1016,6 +1016,32 @@ hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, 
     return hipGetLastError();
 }
 
+// update_reserves!(r) for the two-coin families -- src/router.jl:127-132 with the update the routing
+// problem prescribes (find_arb! docstring, src/cfmms.jl:26-31): R <- (R + γΔ) − Λ, in place, from
+// the trades of the latest materialising sweep; GeometricMean segments refresh {log R₁, log R₂}.
+__global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, const double* __restrict__ gamma,
+                                                       const double2* __restrict__ Delta,
+                                                       const double2* __restrict__ Lambda, double2* __restrict__ lR,
+                                                       long long m)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double g = gamma[i];
+    const double2 r = R[i], d = Delta[i], l = Lambda[i];
+    const double2 rn = make_double2((r.x + g * d.x) - l.x, (r.y + g * d.y) - l.y);
+    R[i] = rn;
+    if (lR) lR[i] = make_double2(log(rn.x), log(rn.y));
+}
+
+hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
+                                  double2* lR, int64_t m, hipStream_t s)
+{
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, lR,
+                       (long long)m);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                                 const PeerSet& ps, hipEvent_t e0, hipEvent_t e1)
 {

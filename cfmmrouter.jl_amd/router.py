@@ -284,15 +284,51 @@ def netflows(r: Router):
     return ψ
 
 
-def update_reserves_(r: Router):
+def update_reserves_(r: Router, sync_host=True):
     """update_reserves!(r) -- src/router.jl:127-132.
 
     The reference's router method calls `update_reserves!(c, Δ, Λ, v)` per pool, a method that is
     defined nowhere (its own test marks it "borked", test/arb.jl:30-39), so there is no reference
-    behaviour to match.  What is implemented here is the update the routing problem itself
-    prescribes (find_arb! docstring, src/cfmms.jl:26-31: the pool ends at R + γΔ − Λ) for the
-    two-coin families; UniV3 pools (whose state is a price and a tick ladder) are not supported.
-    The packed pool store is rebuilt on the device; the trades of the latest sweep are consumed."""
+    behaviour to match.  What is implemented is the update the routing problem itself prescribes
+    (find_arb! docstring, src/cfmms.jl:26-31: the pool ends at R + γΔ − Λ), applied in place on the
+    device from the trades of the latest find_arb!/route! (cfmm_update_reserves): one kernel for the
+    two-coin families; UniV3 pools move to the price the arbitrage left them at.  The trades are
+    consumed.  sync_host=True (default) also refreshes the host mirror (`r.cfmms[i].R`, batch.R,
+    batch.current_price: 16 / 8 bytes per pool device-to-host); sequential routing that never reads
+    them can pass sync_host=False and moves no per-pool data at all."""
+    ctx = getattr(r._backend, "ctx", None)
+    if ctx is None:   # test-injected / sharded backends: host-side update of the two-coin families
+        return _update_reserves_host(r)
+    ctx.update_reserves()
+    if sync_host:
+        seg = 0
+        for b in r._batches:
+            if len(b) == 0:
+                continue
+            if b.kind == KIND_UNIV3:
+                b.current_price[:] = ctx.prices(seg, len(b))
+            else:
+                b.R[:] = ctx.reserves(seg, len(b))
+            seg += 1
+        if isinstance(r.cfmms, list):                     # keep the per-pool objects in step
+            it = iter(range(r._m)) if r._order is None else iter(r._order)
+            for b in r._batches:
+                for k in range(len(b)):
+                    pool = r.cfmms[next(it)]
+                    if b.kind == KIND_UNIV3:
+                        pool.current_price = float(b.current_price[k])
+                        pool.current_tick = int(np.count_nonzero(pool.lower_ticks >= pool.current_price))
+                    else:
+                        pool.R[:] = b.R[k]
+    r._Δs = np.zeros((r._m, 2))
+    r._Λs = np.zeros((r._m, 2))
+    r._psi = np.zeros(r.n_tokens)
+    r._acc = 0.0
+    r._trades_stale = False
+    return None
+
+
+def _update_reserves_host(r: Router):
     if any(b.kind == KIND_UNIV3 for b in r._batches):
         raise NotImplementedError("update_reserves! is not defined for UniV3 pools (nor in the reference)")
     if not hasattr(r._backend, "reload"):

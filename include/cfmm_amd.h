@@ -141,6 +141,23 @@ int cfmm_get_trades(cfmm_ctx* ctx, double* Delta, double* Lambda);
 int cfmm_get_trades_range(cfmm_ctx* ctx, int32_t seg, int64_t first, int64_t count, double* Delta,
                           double* Lambda);
 
+/* update_reserves!(r) -- src/router.jl:127-132.  The reference's router method calls a per-pool
+ * update_reserves!(c, Δ, Λ, v) that is defined nowhere (its own test is disabled, test/arb.jl:30-39);
+ * implemented here is the update the routing problem prescribes (find_arb! docstring,
+ * src/cfmms.jl:26-31: the pool ends at R + γΔ − Λ), applied IN PLACE ON THE DEVICE from the trades of
+ * the latest materialising sweep (cfmm_find_arb, cfmm_route; consumed by this call):
+ *   ProductTwoCoin / GeometricMeanTwoCoin:  R <- (R + γΔ) − Λ            (one kernel, no host traffic)
+ *   UniV3 / BoundedProduct: the state is the price.  A pool that traded moves to the internal price
+ *     P = p/γ (price falling, src/cfmms.jl:361) or γ·p (price rising, :381), p = v₁/v₂, clamped to the
+ *     first tick's upper price; its tick constants are re-derived as at upload (:294-313).  That is
+ *     exactly the pool R + γΔ − Λ tick by tick (tested), and needs the prices of the trades: the
+ *     materialising sweep must have been a host-pointer call.
+ * Afterwards a sweep at the same prices finds no arbitrage in any pool. */
+int cfmm_update_reserves(cfmm_ctx* ctx);
+/* Current reserves R[m][2] of a two-coin segment / current prices [m] of a UniV3 segment. */
+int cfmm_get_reserves(cfmm_ctx* ctx, int32_t seg, double* R);
+int cfmm_get_prices(cfmm_ctx* ctx, int32_t seg, double* current_price);
+
 /* netflows!(psi, r) -- src/router.jl:111-119, for the most recent sweep. */
 int cfmm_netflows(cfmm_ctx* ctx, double* psi);
 /* the `acc` of fn (src/router.jl:79-83) for the most recent sweep. */
