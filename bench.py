@@ -142,6 +142,9 @@ def route_leg(name, batches, n):
             times.append(time.perf_counter() - t0)
         out[key] = 1e3 * min(times)
         out["evaluations" if solver == "scipy" else "native_evaluations"] = r.info.get("funcalls")
+        if solver == "native":   # where the one-call route! spends its time: device sweeps vs the host L-BFGS-B
+            out["native_sweep_ms"] = 1e3 * r.info["sweep_seconds"]
+            out["native_host_solver_ms"] = 1e3 * (r.info["total_seconds"] - r.info["sweep_seconds"])
         out["_psi" if solver == "scipy" else "_psi_native"] = cr.netflows(r).copy()
     r.close()
     return out

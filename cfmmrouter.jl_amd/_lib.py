@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfmm_amd.so")
+LIB_PATH = os.environ.get("CFMM_AMD_LIB") or os.path.join(_HERE, "libcfmm_amd.so")   # override: A/B builds in scripts/
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
@@ -34,7 +34,8 @@ OBJ_LINEAR_NONNEGATIVE, OBJ_BASKET_LIQUIDATION = 0, 1
 
 class RouteInfo(C.Structure):
     _fields_ = [("f", C.c_double), ("proj_grad", C.c_double), ("iterations", C.c_int32),
-                ("evaluations", C.c_int32), ("sweeps", C.c_int32), ("status", C.c_int32)]
+                ("evaluations", C.c_int32), ("sweeps", C.c_int32), ("status", C.c_int32),
+                ("sweep_seconds", C.c_double), ("total_seconds", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -1514,6 +1515,8 @@ int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double
         info->evaluations = r.evaluations;
         info->sweeps = r.evaluations;
         info->status = r.status;
+        info->sweep_seconds = 0.0;
+        info->total_seconds = 0.0;
     }
     return CFMM_OK;
 }
@@ -1547,9 +1550,17 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     for (int j = 0; j < n; ++j) rv[j] = v0 ? v0[j] : 1.0 / n; // src/router.jl:61-65
 
     int sweeps = 0, rc_inner = CFMM_OK;
-    auto sweep = [&](const double* x) { // fused evaluation: Ψ and acc into c->last_out
-        rc_inner = host_sweep(c, x, false);
+    double sweep_s = 0.0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto timed_sweep = [&](const double* x, bool mat) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = host_sweep(c, x, mat);
+        sweep_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ++sweeps;
+        return rc;
+    };
+    auto sweep = [&](const double* x) { // fused evaluation: Ψ and acc into c->last_out
+        rc_inner = timed_sweep(x, false);
         return rc_inner == CFMM_OK;
     };
     // f(objective, v) and grad!(G, objective, v): src/objectives.jl:62-76, :106-121
@@ -1591,8 +1602,7 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     opt.boxed_from_nbd = true; // bounds[1,:] .= 2 with an infinite upper limit: the Fortran's "boxed" path
     LbfgsbResult r = lbfgsb_minimize(n, v.data(), lo.data(), up.data(), nbd.data(), fg, opt); // :105
     if (rc_inner != CFMM_OK) return rc_inner;
-    int rc = host_sweep(c, v.data(), true); // src/router.jl:106-107: r.v = v*, find_arb!(r, v*)
-    ++sweeps;
+    int rc = timed_sweep(v.data(), true); // src/router.jl:106-107: r.v = v*, find_arb!(r, v*)
     if (rc != CFMM_OK) return rc;
     if (v_out) std::copy(v.begin(), v.end(), v_out);
     if (psi_out) std::memcpy(psi_out, c->last_out.data(), (size_t)n * sizeof(double));
@@ -1603,6 +1613,8 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
         info->evaluations = r.evaluations;
         info->sweeps = sweeps;
         info->status = r.status;
+        info->sweep_seconds = sweep_s;
+        info->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return CFMM_OK;
 }

@@ -15,13 +15,6 @@ constexpr double kInf = std::numeric_limits<double>::infinity();
 inline bool has_lower(int nbd) { return nbd == 1 || nbd == 2; }
 inline bool has_upper(int nbd) { return nbd == 2 || nbd == 3; }
 
-double dot(const std::vector<double>& a, const std::vector<double>& b)
-{
-    double s = 0.0;
-    for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
-    return s;
-}
-
 // Dense k×k solve A·X = B (B has nrhs columns, row-major), Gaussian elimination with partial
 // pivoting.  k = 2·col <= 2·m is tiny.
 bool solve_dense(std::vector<double> A, std::vector<double>& B, int k, int nrhs)
@@ -180,42 +173,80 @@ struct MoreThuente {
 };
 
 // ---- limited-memory matrices --------------------------------------------------------------------
+// Storage is laid out for the per-iteration hot loops (n = a few hundred, m = 5): S and Y are kept
+// TRANSPOSED, Yt[i][j] = (y_j)_i with row pitch m, so that row i of W = [Y θS] -- what the Cauchy
+// search and the subspace step touch per variable -- is two short contiguous runs.
 struct Memory {
     int n = 0, m = 0, col = 0;
     double theta = 1.0;
-    std::vector<std::vector<double>> S, Y; // col columns of length n, oldest first
-    std::vector<double> SY, SS;            // m×m, row-major, [i][j] = s_i'y_j / s_i's_j (valid for i,j < col)
+    std::vector<double> St, Yt;            // n×m row-major, columns [0, col) valid, oldest first
+    std::vector<double> SY, SS, YY;        // m×m, row-major, [i][j] = s_i'y_j / s_i's_j / y_i'y_j (valid for i,j < col)
     std::vector<double> M;                 // (2col)×(2col) = K^{-1}, K = [[-D, L'],[L, θ S'S]]
+    std::vector<double> K;                 // scratch
+
+    void init(int n_, int m_)
+    {
+        n = n_;
+        m = m_;
+        St.assign((size_t)n * m, 0.0);
+        Yt.assign((size_t)n * m, 0.0);
+        SY.assign((size_t)m * m, 0.0);
+        SS.assign((size_t)m * m, 0.0);
+        YY.assign((size_t)m * m, 0.0);
+    }
 
     void reset()
     {
         col = 0;
         theta = 1.0;
-        S.clear();
-        Y.clear();
     }
 
     void push(const std::vector<double>& s, const std::vector<double>& y, double sy, double yy)
     {
-        if (col == m) { // drop the oldest pair
-            S.erase(S.begin());
-            Y.erase(Y.begin());
+        if (col == m) { // drop the oldest pair: shift the columns left by one
+            for (int i = 0; i < n; ++i) {
+                double* sr = &St[(size_t)i * m];
+                double* yr = &Yt[(size_t)i * m];
+                for (int j = 0; j + 1 < m; ++j) { sr[j] = sr[j + 1]; yr[j] = yr[j + 1]; }
+            }
             for (int i = 0; i + 1 < m; ++i)
                 for (int j = 0; j + 1 < m; ++j) {
                     SY[i * m + j] = SY[(i + 1) * m + j + 1];
                     SS[i * m + j] = SS[(i + 1) * m + j + 1];
+                    YY[i * m + j] = YY[(i + 1) * m + j + 1];
                 }
             --col;
         }
-        S.push_back(s);
-        Y.push_back(y);
         const int k = col;
-        for (int i = 0; i <= k; ++i) {
-            SY[i * m + k] = dot(S[i], y);
-            SY[k * m + i] = dot(s, Y[i]);
-            SS[i * m + k] = SS[k * m + i] = dot(S[i], s);
+        double sS[16], sY[16], yS[16], yY[16];   // inner products of the new pair with the stored ones (m <= 16 here)
+        std::vector<double> big;
+        double *dsS = sS, *dsY = sY, *dyS = yS, *dyY = yY;
+        if (m > 16) { big.assign((size_t)4 * m, 0.0); dsS = big.data(); dsY = dsS + m; dyS = dsY + m; dyY = dyS + m; }
+        for (int j = 0; j < k; ++j) dsS[j] = dsY[j] = dyS[j] = dyY[j] = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double* sr = &St[(size_t)i * m];
+            double* yr = &Yt[(size_t)i * m];
+            const double si = s[i], yi = y[i];
+            for (int j = 0; j < k; ++j) {
+                dsS[j] += si * sr[j];
+                dsY[j] += si * yr[j];
+                dyS[j] += yi * sr[j];
+                dyY[j] += yi * yr[j];
+            }
+            sr[k] = si;
+            yr[k] = yi;
+        }
+        double ss = 0.0;
+        for (int i = 0; i < n; ++i) ss += s[i] * s[i];
+        for (int j = 0; j < k; ++j) {
+            SY[j * m + k] = dyS[j];          // s_j'y_new
+            SY[k * m + j] = dsY[j];          // s_new'y_j
+            SS[j * m + k] = SS[k * m + j] = dsS[j];
+            YY[j * m + k] = YY[k * m + j] = dyY[j];
         }
         SY[k * m + k] = sy;
+        SS[k * m + k] = ss;
+        YY[k * m + k] = yy;
         ++col;
         theta = yy / sy;
         form_M();
@@ -224,7 +255,7 @@ struct Memory {
     bool form_M()
     {
         const int k = 2 * col;
-        std::vector<double> K((size_t)k * k, 0.0);
+        K.assign((size_t)k * k, 0.0);
         for (int i = 0; i < col; ++i) {
             K[i * k + i] = -SY[i * m + i]; // -D
             for (int j = 0; j < col; ++j) {
@@ -241,12 +272,27 @@ struct Memory {
     }
 
     // row b of W = [Y θS]
-    void w_row(int b, std::vector<double>& w) const
+    void w_row(int b, double* w) const
     {
+        const double* yr = &Yt[(size_t)b * m];
+        const double* sr = &St[(size_t)b * m];
         for (int j = 0; j < col; ++j) {
-            w[j] = Y[j][b];
-            w[col + j] = theta * S[j][b];
+            w[j] = yr[j];
+            w[col + j] = theta * sr[j];
         }
+    }
+    // W'W = [[Y'Y, θ Y'S], [θ S'Y, θ² S'S]]  (2col × 2col, row-major)
+    void WtW(std::vector<double>& out) const
+    {
+        const int k = 2 * col;
+        out.assign((size_t)k * k, 0.0);
+        for (int i = 0; i < col; ++i)
+            for (int j = 0; j < col; ++j) {
+                out[i * k + j] = YY[i * m + j];
+                out[i * k + col + j] = theta * SY[j * m + i];          // y_i's_j
+                out[(col + i) * k + j] = theta * SY[i * m + j];        // s_i'y_j
+                out[(col + i) * k + col + j] = theta * theta * SS[i * m + j];
+            }
     }
     void M_times(const std::vector<double>& v, std::vector<double>& out) const
     {
@@ -305,14 +351,14 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
     if (opt.boxed_from_nbd) boxed = boxed_as_given;
 
     Memory mem;
-    mem.n = n;
-    mem.m = m;
-    mem.SY.assign((size_t)m * m, 0.0);
-    mem.SS.assign((size_t)m * m, 0.0);
+    mem.init(n, m);
 
     std::vector<double> g(n), g_old(n), x_old(n), xcp(n), z(n), d(n), t(n), s(n), y(n);
     std::vector<double> p, c, wb, v1, v2, Mc;
-    std::vector<int> order, fixed(n);
+    std::vector<double> r, du, wzr, WZ, vv, N;   // subspace-step scratch, reused across iterations
+    std::vector<int> order, fixed(n), free_idx;
+    order.reserve(n);
+    free_idx.reserve(n);
 
     auto evaluate = [&](double* xx, double* gg) -> double {
         ++res.evaluations;
@@ -371,11 +417,21 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 }
                 xcp[i] = x[i];
             }
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a] < t[b]; });
-            for (int j = 0; j < col; ++j) {
-                p[j] = dot(mem.Y[j], d);
-                p[col + j] = theta * dot(mem.S[j], d);
+            // breakpoints are consumed in increasing order, usually only the first few: a min-heap
+            // (the Fortran's hpsolb) instead of a full sort
+            auto later = [&](int a, int b) { return t[a] > t[b] || (t[a] == t[b] && a > b); };
+            std::make_heap(order.begin(), order.end(), later);
+            for (int i = 0; i < n; ++i) {   // p = W'd
+                const double di = d[i];
+                if (di == 0.0) continue;
+                const double* yr = &mem.Yt[(size_t)i * m];
+                const double* sr = &mem.St[(size_t)i * m];
+                for (int j = 0; j < col; ++j) {
+                    p[j] += yr[j] * di;
+                    p[col + j] += sr[j] * di;
+                }
             }
+            for (int j = 0; j < col; ++j) p[col + j] *= theta;
             double fp = -dtd;
             double fpp = -theta * fp;
             if (col > 0) {
@@ -385,15 +441,16 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             const double fpp_org = fpp;
             double dt_min = fpp > 0.0 ? -fp / fpp : 0.0;
             double t_old = 0.0;
-            size_t next = 0;
+            size_t heap_end = order.size();
             bool all_fixed = moving == 0;
-            while (!all_fixed && next < order.size()) {
-                const int b = order[next];
+            while (!all_fixed && heap_end > 0) {
+                const int b = order.front();
                 const double tb = t[b];
                 const double dt = tb - t_old;
                 if (dt_min < dt) break;
                 // variable b reaches its bound
-                ++next;
+                std::pop_heap(order.begin(), order.begin() + heap_end, later);
+                --heap_end;
                 const double gb = g[b];
                 xcp[b] = d[b] > 0.0 ? u[b] : l[b];
                 const double zb = xcp[b] - x[b];
@@ -403,7 +460,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 fp += dt * fpp + gb * gb + theta * gb * zb;
                 fpp -= theta * gb * gb;
                 if (col > 0) {
-                    mem.w_row(b, wb);
+                    mem.w_row(b, wb.data());
                     mem.M_times(c, v1);       // M c
                     mem.M_times(p, v2);       // M p
                     double wMc = 0, wMp = 0, wMw = 0;
@@ -430,34 +487,57 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
 
         // ---------------- subspace minimization (BLNZ95 §5.1 direct primal + MN11 projection) -----
         for (int i = 0; i < n; ++i) z[i] = xcp[i];
-        std::vector<int> free_idx;
+        free_idx.clear();
         for (int i = 0; i < n; ++i)
             if (!fixed[i]) free_idx.push_back(i);
         if (col > 0 && !free_idx.empty()) {
             const int nf = (int)free_idx.size();
             // r = Z'(g + θ(xcp − x) − W M c)
-            std::vector<double> r(nf);
+            r.resize(nf);
             mem.M_times(c, Mc);
+            for (int j = 0; j < col; ++j) Mc[col + j] *= theta;   // fold θ of W = [Y θS] into the coefficients
+            wzr.assign(k2, 0.0);
             for (int a = 0; a < nf; ++a) {
                 const int i = free_idx[a];
+                const double* yr = &mem.Yt[(size_t)i * m];
+                const double* sr = &mem.St[(size_t)i * m];
                 double wmc = 0.0;
-                for (int j = 0; j < col; ++j) wmc += mem.Y[j][i] * Mc[j] + theta * mem.S[j][i] * Mc[col + j];
-                r[a] = g[i] + theta * (xcp[i] - x[i]) - wmc;
-            }
-            // v = M W'Z r ;  N = I − (1/θ) M (W'Z Z'W) ;  v = N^{-1} v
-            std::vector<double> wzr(k2, 0.0), WZ((size_t)k2 * k2, 0.0);
-            for (int a = 0; a < nf; ++a) {
-                const int i = free_idx[a];
-                for (int j = 0; j < col; ++j) {
-                    wb[j] = mem.Y[j][i];
-                    wb[col + j] = theta * mem.S[j][i];
-                }
-                for (int j = 0; j < k2; ++j) {
-                    wzr[j] += wb[j] * r[a];
-                    for (int q = 0; q < k2; ++q) WZ[j * k2 + q] += wb[j] * wb[q];
+                for (int j = 0; j < col; ++j) wmc += yr[j] * Mc[j] + sr[j] * Mc[col + j];
+                const double ra = g[i] + theta * (xcp[i] - x[i]) - wmc;
+                r[a] = ra;
+                for (int j = 0; j < col; ++j) {      // W'Z r
+                    wzr[j] += yr[j] * ra;
+                    wzr[col + j] += sr[j] * ra;
                 }
             }
-            std::vector<double> v(k2), N((size_t)k2 * k2, 0.0);
+            for (int j = 0; j < col; ++j) wzr[col + j] *= theta;
+            // W'Z Z'W: a sum of k2×k2 outer products over the FREE variables -- or, when fewer variables are
+            // fixed than free (the usual case away from a corner of the box), W'W from the stored inner
+            // products minus the outer products of the FIXED rows: O(min(free, fixed)·(2m)²) instead of O(n·(2m)²)
+            const int nfix = n - nf;
+            if (nfix < nf) {
+                mem.WtW(WZ);
+                for (int i = 0; i < n; ++i) {
+                    if (!fixed[i]) continue;
+                    mem.w_row(i, wb.data());
+                    for (int j = 0; j < k2; ++j) {
+                        const double wj = wb[j];
+                        for (int q = 0; q < k2; ++q) WZ[j * k2 + q] -= wj * wb[q];
+                    }
+                }
+            } else {
+                WZ.assign((size_t)k2 * k2, 0.0);
+                for (int a = 0; a < nf; ++a) {
+                    mem.w_row(free_idx[a], wb.data());
+                    for (int j = 0; j < k2; ++j) {
+                        const double wj = wb[j];
+                        for (int q = 0; q < k2; ++q) WZ[j * k2 + q] += wj * wb[q];
+                    }
+                }
+            }
+            std::vector<double>& v = vv;
+            v.assign(k2, 0.0);
+            N.assign((size_t)k2 * k2, 0.0);
             mem.M_times(wzr, v);
             for (int i = 0; i < k2; ++i)
                 for (int j = 0; j < k2; ++j) {
@@ -467,11 +547,14 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 }
             if (solve_dense(N, v, k2, 1)) {
                 // d̂ = −(1/θ) r − (1/θ²) Z'W v
-                std::vector<double> du(nf);
+                du.resize(nf);
+                for (int j = 0; j < col; ++j) v[col + j] *= theta;
                 for (int a = 0; a < nf; ++a) {
                     const int i = free_idx[a];
+                    const double* yr = &mem.Yt[(size_t)i * m];
+                    const double* sr = &mem.St[(size_t)i * m];
                     double wv = 0.0;
-                    for (int j = 0; j < col; ++j) wv += mem.Y[j][i] * v[j] + theta * mem.S[j][i] * v[col + j];
+                    for (int j = 0; j < col; ++j) wv += yr[j] * v[j] + sr[j] * v[col + j];
                     du[a] = -r[a] / theta - wv / (theta * theta);
                 }
                 // MN11: project the subspace minimizer onto the box; keep it if it is a descent

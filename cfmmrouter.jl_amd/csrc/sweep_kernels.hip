@@ -96,7 +96,9 @@ struct ProductOps {
             t.d2 = p1 ? 0.0 : d;
             t.l1 = p1 ? 0.0 : l;
             t.l2 = p1 ? l : 0.0;
-        } else if (p1) {   // both within the margin (γ ≈ 1 at the no-arbitrage price) or NaN inputs
+        } else if (p1 || a != a || b != b) {
+            // both directions within the margin (γ ≈ 1 at the no-arbitrage price), or a NaN among the inputs
+            // (both predicates are false on NaN): the reference's four forms, which propagate it
             solve_full(R1, R2, g, v1, v2, t);
         }
     }
@@ -163,8 +165,9 @@ struct GeoMeanOps {
 //     ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = exp((l_a + e·(l_b − l_c + l_a)) / (1+e))
 // Everything that does not depend on v and is worth its bytes is prepared once at upload
 // (cfmm_abi.hip): η = w₁/w₂, log R₁, log R₂ (1/(η+1) is recomputed: a division is cheaper than 8 B).  Direction 2 uses e = 1/η, for which the two exponents become
-// (η·l_c + l_b)/(η+1) and (η·l_a + (l_b − l_c) + l_a)/(η+1) -- no further division.  Per trading
-// pool that leaves 1 log + 2 exp + 2 divisions (c and the final /γ) instead of 4 pow + 6
+// (η·l_c + l_b)/(η+1) and (η·l_a + (l_b − l_c) + l_a)/(η+1).  The second form is not evaluated at all:
+// the two new reserves stand in the ratio c/r_a fixed by the market price, so it equals the first
+// result times r_a/c.  Per trading pool that leaves 1 log + 1 exp + 4 divisions instead of 4 pow + 6
 // divisions; pools inside the no-arbitrage band cost two multiplies and a compare.
 // The exponent carries an absolute rounding error of a few 1e-16·max(1, η·|l|)/(η+1), so trades
 // agree with the reference-order forms to ~1e-15 of the reserve scale (asserted at 1e-12 in
@@ -190,6 +193,7 @@ struct GeoMeanLogOps {
         const double n2 = (g * v1) * R1, d2 = v2 * eta;     // c₂ = n2/d2: direction 2 trades iff c₂ > R₂
         const bool p1 = n1 > R1 * d1, p2 = n2 > R2 * d2;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (v1 != v1 || v2 != v2) { t.d1 = t.d2 = t.l1 = t.l2 = v1 + v2; return; }   // NaN prices propagate (reference: pow of NaN)
         // pass 0: the (normally only) live direction.  pass 1: direction 2 when BOTH are live, which
         // needs γ > 1 -- kept as a second trip through the same code (not a second copy of it) so the
         // kernel's register footprint is that of one direction.
@@ -197,15 +201,19 @@ struct GeoMeanLogOps {
         for (int pass = 0; pass < 2; ++pass) {
             const bool dir1 = pass == 0 && p1;
             if (pass == 0 ? !(p1 || p2) : !(p1 && p2)) break;
-            const double lc = log((dir1 ? n1 : n2) / (dir1 ? d1 : d2));
+            const double c = (dir1 ? n1 : n2) / (dir1 ? d1 : d2);
+            const double lc = log(c);
             const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
-            const double la = dir1 ? r.lR.y : r.lR.x, lb = dir1 ? r.lR.x : r.lR.y;
-            const double u = (lb - lc) + la;
+            const double lb = dir1 ? r.lR.x : r.lR.y;
             const double A = dir1 ? (lc + eta * lb) : (eta * lc + lb);
-            const double B = dir1 ? (la + eta * u) : (eta * la + u);
-            const double inv = 1.0 / (eta + 1.0);
-            const double d = max0(exp(A * inv) - rb) / g;
-            const double l = max0(ra - exp(B * inv));
+            const double X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
+            // the received side's reserve after the trade is X·r_a/c: at the optimum the pool's marginal
+            // price equals the (fee-adjusted) market price, which fixes the RATIO of the new reserves --
+            // ((r_b·r_a^(1/e))/(e·γ·m))^(e/(1+e)) = X·r_a/c identically -- so the second exp of the
+            // log-space form is one division
+            const double Y = X * (ra / c);
+            const double d = max0(X - rb) / g;
+            const double l = max0(ra - Y);
             if (dir1) { t.d1 = d; t.l2 = l; }
             else { t.d2 = d; t.l1 = l; }
         }
@@ -268,6 +276,7 @@ struct UniV3Ops {
         const double cp = r.pg.x, g = r.pg.y;
         const double pr = v1 / v2;                                     // :340
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        if (pr != pr) { t.d1 = t.d2 = t.l1 = t.l2 = pr; return; }      // NaN prices propagate instead of "no trade"
         if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
         const bool up = pr < g * cp;                                   // :351
         const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
@@ -320,14 +329,16 @@ struct UniV3CoopOps : UniV3Ops {
     {
         const int lane = threadIdx.x & 63;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        bool trades = false, up = false, pending = false;
+        bool trades = false, up = false, pending = false, nan_price = false;
         double g = 1.0, price = 1.0, sd = 0.0, sl = 0.0;
         int next = 0, remaining = 0;                                   // walk-list cursor of this lane's pool
         if (valid) {
             const double cp = r.pg.x;
             g = r.pg.y;
             const double pr = v1 / v2;                                 // :340
-            if (!(g * cp <= pr && pr <= cp / g)) {                     // :347-349
+            if (pr != pr) {                                            // NaN prices propagate instead of "no trade"
+                nan_price = true;
+            } else if (!(g * cp <= pr && pr <= cp / g)) {              // :347-349
                 trades = true;
                 up = pr < g * cp;                                      // :351
                 price = up ? pr / g : 1.0 / (g * pr);                  // :361 / :381
@@ -401,6 +412,7 @@ struct UniV3CoopOps : UniV3Ops {
             if (up) { t.d1 = sd / g; t.l2 = sl; }                      // :366-372
             else { t.d2 = sd / g; t.l1 = sl; }                         // :386-391
         }
+        if (nan_price) t.d1 = t.d2 = t.l1 = t.l2 = __builtin_nan("");
     }
 };
 
@@ -492,9 +504,11 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     if constexpr (U == 1) {
         // One pool per lane per tile.  The first tile's pool state is requested before v and the
         // bins are staged in LDS, so that HBM round trip is not exposed behind the barrier.
-        // (Register double-buffering the following tiles was measured 10 % SLOWER on MI355X: the
-        // 16 resident wavefronts per CU already overlap each other's loads, the extra live
-        // registers only cost occupancy.)
+        // (Requesting tile k+1 before solving tile k was measured twice: round 1, -10 %; round 2 with an
+        // UNCONDITIONAL next-tile load -- a conditional one makes the compiler wait for it at the join,
+        // before the arithmetic -- and the overlap verified in the ISA: +-0 on every workload, with or
+        // without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt).  Not kept: it
+        // only costs registers.)
         const int64_t stride = (int64_t)nblocks * kBlock;
         int64_t i = (int64_t)bid * kBlock + tid;
         typename Ops::Raw cur = {};

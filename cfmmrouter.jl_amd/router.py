@@ -26,6 +26,9 @@ from ._lib import KIND_GEOMEAN, KIND_PRODUCT, KIND_UNIV3, ArgumentError, Context
 from .cfmms import CFMM, PoolBatch, _upload
 
 
+_BOXED_INF = 1e100   # stands in for the reference's u = Inf under nbd = 2 (see route_)
+
+
 class DeviceBackend:
     """The pool store + sweeps of one GPU, behind the C ABI (include/cfmm_amd.h)."""
 
@@ -196,7 +199,10 @@ def route_(r: Router, v=None, verbose=False, m=5, factr=1e1, pgtol=1e-5, maxfun=
         r.v[:] = v  # :64
     lo = _obj.lower_limit(r.objective)  # :67-70 (nbd = 2 with an infinite upper bound)
     up = _obj.upper_limit(r.objective)
-    bounds = [(lo[j], None if math.isinf(up[j]) else up[j]) for j in range(n)]
+    # nbd = 2 with u = Inf makes the Fortran code take its "boxed" unit first step; SciPy would turn an
+    # infinite bound into "no bound" (first step min(1/|d|, 1)), so the reference's call shape is kept
+    # with a finite upper bound no iterate can reach (solver="native" emulates the same thing directly).
+    bounds = [(lo[j], _BOXED_INF if math.isinf(up[j]) else up[j]) for j in range(n)]
 
     def sweep(x):
         r._psi, r._acc = r._backend.eval(x)
@@ -242,7 +248,8 @@ def _route_native(r: Router, v, m, factr, pgtol, maxfun, maxiter):
         r._trades_stale = True
         r.n_sweeps += info["sweeps"]
         r.info = {"f": info["f"], "funcalls": info["evaluations"], "nit": info["iterations"],
-                  "warnflag": 0 if info["status"] in (0, 1) else 2, "task": info["status"], "solver": "native"}
+                  "warnflag": 0 if info["status"] in (0, 1) else 2, "task": info["status"], "solver": "native",
+                  "sweep_seconds": info["sweep_seconds"], "total_seconds": info["total_seconds"]}
         return None
     # any other backend (sharded, test-injected): same solver, Python callback per evaluation
     r.v[:] = np.ones(n) / n if v is None else v

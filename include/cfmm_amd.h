@@ -222,6 +222,8 @@ typedef struct cfmm_route_info {
     int32_t evaluations; /* fn/g! evaluations == device sweeps inside the solver */
     int32_t sweeps;      /* all device sweeps incl. prologue and epilogue (src/router.jl:104,107) */
     int32_t status;      /* 0 pgtol, 1 factr, 2 maxiter, 3 maxfun, 4 line search, 5 non-finite f */
+    double sweep_seconds;  /* wall time spent inside device sweeps (launch to results on the host), all sweeps */
+    double total_seconds;  /* wall time of the whole call; the difference is the host-side L-BFGS-B */
 } cfmm_route_info;
 
 /* route!(r; v, m, factr, pgtol, maxfun, maxiter) -- src/router.jl:58-108, with the external

@@ -165,6 +165,8 @@ struct RouteInfo
     evaluations::Int32
     sweeps::Int32
     status::Int32
+    sweep_seconds::Float64
+    total_seconds::Float64
 end
 
 function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000)
@@ -178,7 +180,7 @@ function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxf
     end
     n = length(r.v)
     vout = Vector{Float64}(undef, n)
-    info = Ref(RouteInfo(0.0, 0.0, 0, 0, 0, 0))
+    info = Ref(RouteInfo(0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0))
     v0vec = isnothing(v) ? Float64[] : Vector{Float64}(v)
     GC.@preserve vec v0vec vout check(r.ctx, ccall((:cfmm_route, LIB), Cint,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Float64, Float64, Int32, Int32,

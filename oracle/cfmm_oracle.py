@@ -349,6 +349,9 @@ class PoolSet:
         return np.concatenate(Ds), np.concatenate(Ls)
 
 
+BOXED_INF = 1e100   # "u = Inf with nbd = 2": see route_oracle
+
+
 def route_oracle(objective, pools: PoolSet, v0=None, m=5, factr=1e1, pgtol=1e-5, maxfun=15000,
                  maxiter=15000, nthreads=1):
     """route!(r; v, m, factr, pgtol, maxfun, maxiter) -- src/router.jl:58-108.
@@ -364,7 +367,12 @@ def route_oracle(objective, pools: PoolSet, v0=None, m=5, factr=1e1, pgtol=1e-5,
         state["sweeps"] += 1
 
     lo = objective.lower_limit()  # :67-70 (nbd=2 with u=Inf == SciPy's nbd=1)
-    bounds = [(lo[j], None) for j in range(n)]
+    # The reference passes nbd = 2 for every variable with an INFINITE upper bound (src/router.jl:67-70); the
+    # Fortran code then treats the problem as "boxed" and takes a unit first step.  SciPy maps an infinite
+    # bound to "no bound" (nbd = 1, first step min(1/|d|, 1)), so the reference's call shape is reproduced
+    # with a finite upper bound no iterate can reach.
+    up = objective.upper_limit() if hasattr(objective, "upper_limit") else np.full(n, np.inf)
+    bounds = [(lo[j], up[j] if np.isfinite(up[j]) else BOXED_INF) for j in range(n)]
 
     def fg(v):
         if not np.all(v == state["v"]):  # :74-77 / :92-95 (one sweep per evaluation)

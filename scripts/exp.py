@@ -23,6 +23,12 @@ for spec in sys.argv[2:] or [""]:
     for kv in filter(None, spec.split(",")):
         k, val = kv.split("="); be.ctx.set_option(k, int(val))
     res = []
+    warm_s = float(os.environ.get("WARM_S", "0"))
+    if warm_s > 0:   # sustained load first: lets the clock governor ramp (DVFS) before anything is timed
+        t_end = time.perf_counter() + warm_s
+        while time.perf_counter() < t_end:
+            for _ in range(200): be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), True)
+            torch.cuda.synchronize()
     for mat in (True, False):
         for _ in range(20): be.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), mat)
         torch.cuda.synchronize()

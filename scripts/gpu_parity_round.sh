@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_update.py -m gpu -x -q > gpurun_out/pytest_update.log 2>&1 < /dev/null; tail -30 gpurun_out/pytest_update.log
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 < /dev/null; tail -15 gpurun_out/pytest_gpu.log
+timeout 300 python scripts/exp.py config3 "" "geomean_exact=1" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/exp_geo.txt

@@ -128,3 +128,31 @@ def test_sequential_routing_full_size_without_host_trade_traffic():
         assert np.max(np.abs(R[:, 0] * R[:, 1] - k0) / k0) < 1e-9   # the invariant is unchanged
     finally:
         r.close()
+
+
+def test_nan_prices_propagate_through_device_pointer_sweeps():
+    """cfmm_sweep_dev takes v from device memory and cannot validate it; a NaN price must come
+    back as NaN trades / netflows (the reference propagates NaN), never as a plausible-looking zero."""
+    import torch
+    n = 12
+    batches = [synth.product_pools(3000, n, seed=1), synth.geomean_pools(2000, n, seed=2),
+               synth.univ3_pools(1000, n, 4, seed=3)]
+    be = cr.DeviceBackend(n, batches)
+    try:
+        v = synth.sweep_prices(n, seed=4)
+        v[5] = np.nan
+        vt = torch.from_numpy(v).cuda()
+        out = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        be.ctx.sweep_dev(vt.data_ptr(), out.data_ptr(), True)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.isnan(o[5]) and np.isnan(o[n])
+        D, L = be.trades()
+        Ai = np.concatenate([b.Ai for b in batches])
+        touches = np.any(Ai == 6, axis=1)                 # 1-based token 6 == index 5
+        assert np.all(np.isnan(D[touches]).any(axis=1) | np.isnan(L[touches]).any(axis=1))
+        assert not np.isnan(D[~touches]).any() and not np.isnan(L[~touches]).any()
+        with pytest.raises(cr.ArgumentError):             # host-pointer calls validate v instead
+            be.find_arb(v)
+    finally:
+        be.close()
