@@ -71,6 +71,10 @@ struct Group {
     int block = kSmallBlock;
     int grid = 0;       // total blocks of the launch
     int64_t row_off = 0;
+    // XCD-aware weighted block -> segment map of a fused launch (see sweep_multi); xcd_map == false: block b -> segment b % nseg
+    bool xcd_map = false;
+    unsigned char pattern[32] = {0}, rank[32] = {0};
+    int seg_w[kMaxMulti] = {0};
 };
 
 } // namespace
@@ -149,6 +153,11 @@ struct cfmm_ctx {
     int64_t opt_univ3_coop = -1;   // -1 auto (by walk-list length), 0 lane-per-pool only, 1 wavefront-cooperative
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / write Ψ through mapped pinned memory
     int64_t opt_spin_wait = 0;     // 1: host-pointer calls busy-poll the stream (measured: no gain over hipStreamSynchronize)
+    int64_t opt_wave_split = 0;    // 1: fused launches deal each block's wavefronts to the pool families (every block sweeps every segment)
+    int64_t opt_xcd_map = 1;       // fused launches: 1 = XCD-aware block -> segment map weighted by pools x cost per pool,
+                                   // 2 = XCD-aware with equal cost per pool, 0 = block b -> segment b % nseg
+    int64_t opt_cost_geomean = 18; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one
+    int64_t opt_cost_univ3 = 14;
     int64_t opt_inline_fold = 0;   // 1: partial rows are folded inside the sweep launch (single-launch evaluations, n <= kMaxFoldTokens);
                                    //    measured 1-3 us per step SLOWER than the separate fold launch, kept as an option
     int64_t opt_host_flag = 1;     // 1: zero-copy host-pointer sweeps end by raising a flag in mapped host memory that the
@@ -277,6 +286,70 @@ void plan_segment(const cfmm_ctx* c, Segment& s)
 }
 
 bool global_bins(const cfmm_ctx* c) { return c->n > kMaxLdsTokens; }
+
+// Relative cost of one pool evaluation per family, in tenths of a ProductTwoCoin evaluation (options
+// "cost_geomean" / "cost_univ3"; measured on config3 / mixed markets, see DESIGN).  Used only to divide
+// the blocks of a fused launch among its segments so that they finish together.
+int64_t family_cost(const cfmm_ctx* c, const Segment& s)
+{
+    switch (s.kind) {
+    case CFMM_KIND_PRODUCT: return 10;
+    case CFMM_KIND_GEOMEAN: return c->opt_cost_geomean;
+    default: return c->opt_cost_univ3 + (s.m > 0 ? 2 * (s.n_ticks_total / s.m) : 0);   // deeper ladders walk longer
+    }
+}
+
+// XCD-aware, cost-weighted map of a fused launch (grid a multiple of 256 blocks): 32-deal pattern in
+// which segment s appears seg_w[s] times, spread evenly (largest-remainder weights, Bresenham order).
+void plan_xcd_map(cfmm_ctx* c, Group& g)
+{
+    g.xcd_map = false;
+    if (!g.multi || c->opt_xcd_map == 0 || g.grid % 256 != 0 || global_bins(c)) return;
+    double cost[kMaxMulti], total = 0.0;
+    for (int k = 0; k < g.nseg; ++k) {
+        const Segment& s = c->segs[(size_t)g.first + k];
+        cost[k] = (double)s.m * (double)(c->opt_xcd_map == 2 ? 10 : family_cost(c, s));   // 2: equal cost per pool
+        total += cost[k];
+    }
+    if (!(total > 0.0)) return;
+    int w[kMaxMulti], sum = 0;
+    double frac[kMaxMulti];
+    for (int k = 0; k < g.nseg; ++k) {
+        const double share = 32.0 * cost[k] / total;
+        w[k] = std::max(1, (int)share);
+        frac[k] = share - (int)share;
+        sum += w[k];
+    }
+    while (sum < 32) {   // hand the remaining deals to the largest remainders
+        int best = 0;
+        for (int k = 1; k < g.nseg; ++k) if (frac[k] > frac[best]) best = k;
+        ++w[best]; frac[best] = -1.0; ++sum;
+    }
+    while (sum > 32) {   // (only when several tiny segments were rounded up to one deal each)
+        int big = 0;
+        for (int k = 1; k < g.nseg; ++k) if (w[k] > w[big]) big = k;
+        --w[big]; --sum;
+    }
+    // Bresenham spread: at every position pick the segment that is furthest behind its share
+    int given[kMaxMulti] = {0};
+    for (int p = 0; p < 32; ++p) {
+        int best = -1;
+        double lag_best = -1e30;
+        for (int k = 0; k < g.nseg; ++k) {
+            if (given[k] >= w[k]) continue;
+            const double lag = (double)(p + 1) * w[k] / 32.0 - given[k];
+            if (lag > lag_best) { lag_best = lag; best = k; }
+        }
+        g.pattern[p] = (unsigned char)best;
+        g.rank[p] = (unsigned char)given[best];
+        ++given[best];
+    }
+    for (int k = 0; k < g.nseg; ++k) {
+        g.seg_w[k] = w[k];
+        c->segs[(size_t)g.first + k].grid = (g.grid / 256) * w[k] * 8;
+    }
+    g.xcd_map = true;
+}
 int row_width(const cfmm_ctx* c) { return global_bins(c) ? 1 : c->n + 1; }
 
 int bin_copies(const cfmm_ctx* c, int block)
@@ -361,6 +434,7 @@ int ensure_geometry(cfmm_ctx* c)
             const int per_seg = (int)std::min<int64_t>(tiles, cap);
             for (int k = 0; k < g.nseg; ++k) c->segs[first + k].grid = per_seg;
             g.grid = per_seg * g.nseg;
+            plan_xcd_map(c, g);   // may re-divide the same number of blocks among the segments by cost
             g.row_off = rows;
             c->segs[first].row_off = rows;
             rows += g.grid;
@@ -460,6 +534,11 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             MultiArgs ma;
             std::memset(&ma, 0, sizeof ma);
             ma.nseg = g.nseg;
+            ma.xcd_map = g.xcd_map ? 1 : 0;
+            std::memcpy(ma.pattern, g.pattern, sizeof ma.pattern);
+            std::memcpy(ma.rank, g.rank, sizeof ma.rank);
+            for (int k = 0; k < kMaxMulti; ++k) ma.seg_w[k] = g.seg_w[k];
+            ma.wave_split = (c->opt_wave_split != 0 && (g.block / 64) % g.nseg == 0 && !gb) ? 1 : 0;
             ma.common = a;
             ma.common.gflow = gb ? c->d_flow : nullptr; // mode flag for the launcher; per-segment bases below
             for (int k = 0; k < g.nseg; ++k) {
@@ -1077,6 +1156,10 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "univ3_coop")) return &c->opt_univ3_coop;
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
+    if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
+    if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;
+    if (!std::strcmp(key, "cost_univ3")) return &c->opt_cost_univ3;
+    if (!std::strcmp(key, "wave_split")) return &c->opt_wave_split;
     if (!std::strcmp(key, "host_flag")) return &c->opt_host_flag;
     if (!std::strcmp(key, "multi_threads")) return &c->opt_multi_threads;
     return nullptr;
@@ -1101,7 +1184,7 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
             if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
         }
     if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
-        slot == &c->opt_geomean_exact)
+        slot == &c->opt_geomean_exact || slot == &c->opt_xcd_map || slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
         c->geometry_dirty = true;
     return CFMM_OK;
 }

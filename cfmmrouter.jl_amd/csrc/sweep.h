@@ -89,6 +89,14 @@ struct MultiSeg {
 };
 struct MultiArgs {
     int nseg;
+    int xcd_map;                 // 1: XCD-aware, cost-weighted block -> segment map (needs grid % 256 == 0): deal j = b / 8
+                                 //    (the 8 blocks that land on the 8 XCDs together) belongs to segment
+                                 //    pattern[(j + j / 32) % 32] and is that segment's deal number (j / 32)·w + rank[...]
+    unsigned char pattern[32];   // segment of each of 32 consecutive deals; segment s appears seg_w[s] times
+    unsigned char rank[32];      // rank[p] = #{p' < p : pattern[p'] == pattern[p]}
+    int seg_w[kMaxMulti];        // deals out of 32 given to each segment (in proportion to pools x cost per pool)
+    int wave_split;              // 1: every block sweeps every segment, its wavefronts dealt to the families
+                                 //    (needs (block / 64) % nseg == 0)
     MultiSeg seg[kMaxMulti];
     SweepArgs common;            // v, n, n_pad, copies, partials (row 0 of this launch), nt_stores
 };
@@ -109,7 +117,7 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
                         hipStream_t s);
 
-// grid must be a multiple of ma.nseg: block b sweeps segment b % nseg and writes partial row b.
+// grid must be a multiple of ma.nseg; block b writes partial row b (see sweep_multi for the block -> segment map).
 hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool materialize, hipStream_t s);
 
 // Large markets: chunk_sums[c] = sum of flow[entries[chunks[c].x .. chunks[c].y)], then

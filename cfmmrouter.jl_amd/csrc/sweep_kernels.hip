@@ -456,23 +456,49 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 // flows Λ−Δ are written to a flow array; Ψ is then PULLED per token over a token -> (pool, side)
 // incidence list built at upload (gather_chunks / token_fold below) -- no float atomics, fixed
 // summation order.  The partial rows carry only the dual scalar.
-template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
-__device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
+// LDS of a sweeping block: v (the price vector), the netflow bins (one copy per wavefront, or one
+// shared copy) and one slot per wavefront for the dual-scalar fold.
+struct SweepLds {
+    double* v_lds;     // [n_pad]
+    double* bins;      // [copies][n_pad]
+    double* wsum;      // [kWaves]
+    double* my_bins;   // this wavefront's copy
+};
+
+template <int BLOCK, bool GBINS>
+__device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
 {
-    constexpr int kBlock = BLOCK;
-    constexpr int kWaves = BLOCK / 64;
     extern __shared__ double lds[];
-    double* v_lds = lds;                                                      // [n_pad]
-    double* bins = lds + (GBINS ? 0 : a.n_pad);                               // [copies][n_pad]
-    double* wsum = GBINS ? lds : bins + (size_t)a.copies * a.n_pad;           // [kWaves]
+    SweepLds L;
+    L.v_lds = lds;
+    L.bins = lds + (GBINS ? 0 : a.n_pad);
+    L.wsum = GBINS ? lds : L.bins + (size_t)a.copies * a.n_pad;
+    L.my_bins = L.bins + (size_t)(a.copies == 1 ? 0 : (threadIdx.x >> 6)) * a.n_pad;
+    return L;
+}
+
+// v -> LDS, bins <- 0, barrier.  Whole block.
+template <int BLOCK, bool GBINS>
+__device__ __forceinline__ void stage_prices(const SweepArgs& a, const SweepLds& L)
+{
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
     const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
     const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
+    for (int j = tid; j < n_stage; j += BLOCK) L.v_lds[j] = a.v[j];
+    for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+    __syncthreads();
+}
 
-    double* my_bins = bins + (size_t)(a.copies == 1 ? 0 : wave) * a.n_pad;
+// The tile loop of one pool family over a SHARE of a segment: lane `sub_tid` of a group of
+// `sub_block` threads (the whole block, or the wavefronts a fused launch gives this family) takes
+// pools (bid + k·nblocks)·sub_block + sub_tid, k = 0, 1, ...  Returns this lane's dual-scalar part.
+// STAGE: call stage_prices() after the first tile's loads have been issued (hides that HBM round
+// trip behind the staging barrier); otherwise the caller has staged already.
+template <class Ops, bool MAT, int U, int BLOCK, bool GBINS, bool STAGE>
+__device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
+                                              int sub_tid, int sub_block)
+{
     double acc = 0.0;
-
     // `valid` is false only for wave-cooperative families, whose lanes without a pool still have to
     // take part in the wavefront-wide phases of solve_wave.
     auto process = [&](const typename Ops::Raw& raw, int64_t i, bool valid) {
@@ -480,7 +506,7 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         if (valid) tok = ops.tokens(raw);
         double v1, v2;                                   // v[r.cfmms[i].Ai]
         if constexpr (GBINS) { v1 = a.v[tok.x]; v2 = a.v[tok.y]; }
-        else { v1 = v_lds[tok.x]; v2 = v_lds[tok.y]; }
+        else { v1 = L.v_lds[tok.x]; v2 = L.v_lds[tok.y]; }
         Trade t;
         if constexpr (Ops::kWaveCooperative) ops.solve_wave(raw, valid, v1, v2, t);
         else ops.solve(raw, v1, v2, t);
@@ -496,8 +522,8 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         if constexpr (GBINS) {
             a.gflow[i] = make_double2(f1, f2);
         } else {
-            if (f1 != 0.0) atomicAdd(&my_bins[tok.x], f1);   // ds_add_f64
-            if (f2 != 0.0) atomicAdd(&my_bins[tok.y], f2);
+            if (f1 != 0.0) atomicAdd(&L.my_bins[tok.x], f1);   // ds_add_f64
+            if (f2 != 0.0) atomicAdd(&L.my_bins[tok.y], f2);
         }
     };
 
@@ -509,14 +535,12 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
         // before the arithmetic -- and the overlap verified in the ISA: +-0 on every workload, with or
         // without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt).  Not kept: it
         // only costs registers.)
-        const int64_t stride = (int64_t)nblocks * kBlock;
-        int64_t i = (int64_t)bid * kBlock + tid;
+        const int64_t stride = (int64_t)nblocks * sub_block;
+        int64_t i = (int64_t)bid * sub_block + sub_tid;
         typename Ops::Raw cur = {};
         bool ok = i < a.m;
         if (ok) cur = ops.load(i);
-        for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
-        for (int j = tid; j < n_zero; j += kBlock) bins[j] = 0.0;
-        __syncthreads();
+        if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
         if constexpr (Ops::kWaveCooperative) {
             while (__any(ok)) {                          // the wavefront stays together
                 process(cur, i, ok);
@@ -535,45 +559,53 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
             }
         }
     } else {
-        for (int j = tid; j < n_stage; j += kBlock) v_lds[j] = a.v[j];
-        for (int j = tid; j < n_zero; j += kBlock) bins[j] = 0.0;
-        __syncthreads();
-        const int64_t tile_pools = (int64_t)kBlock * U;
+        if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
+        const int64_t tile_pools = (int64_t)sub_block * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {   // block-uniform trip count
-            const int64_t base = tile * tile_pools + tid;
+        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {   // uniform trip count within the group
+            const int64_t base = tile * tile_pools + sub_tid;
             typename Ops::Raw raw[U] = {};
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = base + (int64_t)u * kBlock;
+                const int64_t i = base + (int64_t)u * sub_block;
                 ok[u] = i < a.m;
                 if (ok[u]) raw[u] = ops.load(i);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (Ops::kWaveCooperative || ok[u]) process(raw[u], base + (int64_t)u * kBlock, ok[u]);
+                if (Ops::kWaveCooperative || ok[u]) process(raw[u], base + (int64_t)u * sub_block, ok[u]);
         }
     }
+    return acc;
+}
 
-    // fold the dual scalar: lanes by wave shuffles, waves through LDS, fixed order
+// Block epilogue: fold the dual scalar (lanes by wave shuffles, waves through LDS, fixed order), fold
+// the bin copies in a fixed order and write the block's partial row.
+template <int BLOCK, bool GBINS>
+__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id)
+{
+    constexpr int kBlock = BLOCK;
+    constexpr int kWaves = BLOCK / 64;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((tid & 63) == 0) wsum[wave] = acc;
+    if ((tid & 63) == 0) L.wsum[wave] = acc;
     __syncthreads();
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
     const bool publish = !GBINS && a.fold_blocks > 0;    // the row is folded inside THIS launch
     for (int j = tid; j < n_cols; j += kBlock) {
-        double s = bins[j];
-        for (int c = 1; c < a.copies; ++c) s += bins[(size_t)c * a.n_pad + j];
+        double s = L.bins[j];
+        for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
         if (publish) store_through(row + j, s);
         else row[j] = s;
     }
     if (tid == 0) {
-        double s = wsum[0];
-        for (int w = 1; w < kWaves; ++w) s += wsum[w];
+        double s = L.wsum[0];
+        for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
         if (publish) store_through(row + n_cols, s);
         else row[n_cols] = s;
     }
@@ -588,6 +620,16 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
             __hip_atomic_fetch_add(a.sync + (row_id % kArriveShards) * kSyncStride, 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
+// row goes to partials[row_id].
+template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
+__device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
+{
+    const SweepLds L = carve_lds<BLOCK, GBINS>(a);
+    const double acc = sweep_tiles<Ops, MAT, U, BLOCK, GBINS, true>(ops, a, L, bid, nblocks, (int)threadIdx.x, BLOCK);
+    finish_row<BLOCK, GBINS>(a, L, acc, row_id);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -731,9 +773,64 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         return;
     }
     const int bidx = (int)blockIdx.x - fb;
-    const int sidx = bidx % ma.nseg;
-    const int local = bidx / ma.nseg;
-    const int nblocks = ((int)gridDim.x - fb) / ma.nseg;
+    if (ma.wave_split) {
+        // Every block sweeps a share of EVERY segment: its wavefronts are dealt to the pool families
+        // (nseg = 2, 8 wavefronts: 0-3 ProductTwoCoin, 4-7 GeometricMean), so bandwidth-bound and
+        // arithmetic-bound wavefronts share every CU -- and, because a block's wavefronts go to the
+        // SIMDs in turn, every SIMD -- whatever the dispatcher's block placement is.
+        constexpr int kWaves = BLOCK / 64;
+        const int per = kWaves / ma.nseg;                 // wavefronts per family (host guarantees kWaves % nseg == 0)
+        const int fam = ((int)threadIdx.x >> 6) / per;
+        const int sub_block = per * 64, sub_tid = (int)threadIdx.x - fam * sub_block;
+        const int G = (int)gridDim.x - fb;
+        const MultiSeg& sg = ma.seg[fam];
+        SweepArgs a = ma.common;
+        a.m = sg.m;
+        a.Delta = sg.Delta;
+        a.Lambda = sg.Lambda;
+        a.gflow = sg.gflow;
+        const SweepLds L = carve_lds<BLOCK, GBINS>(a);
+        stage_prices<BLOCK, GBINS>(a, L);
+        double acc = 0.0;
+        switch (sg.kind) {                                // wavefront-uniform
+        case 0:
+            acc = sweep_tiles<ProductOps, MAT, 1, BLOCK, GBINS, false>(ProductOps{sg.pools.p}, a, L, bidx, G, sub_tid, sub_block);
+            break;
+        case 1:
+            acc = sweep_tiles<GeoMeanLogOps, MAT, 1, BLOCK, GBINS, false>(GeoMeanLogOps{sg.pools.g}, a, L, bidx, G, sub_tid, sub_block);
+            break;
+        default:
+            {
+                UniV3CoopOps ops;
+                ops.p = sg.pools.u;
+                acc = sweep_tiles<UniV3CoopOps, MAT, 1, BLOCK, GBINS, false>(ops, a, L, bidx, G, sub_tid, sub_block);
+            }
+            break;
+        }
+        finish_row<BLOCK, GBINS>(a, L, acc, bidx);
+        return;
+    }
+    int sidx, local, nblocks;
+    if (ma.xcd_map) {
+        // XCD-aware, cost-weighted block -> segment map.  Blocks are dealt round-robin to the 8 XCDs (block
+        // b runs on XCD b % 8), so "segment = b % nseg" would put ALL blocks of one pool family on the same
+        // XCDs (nseg = 2: ProductTwoCoin on XCDs 0,2,4,6, GeometricMean on 1,3,5,7 -- half the chip does all
+        // the arithmetic).  Here the 8 blocks of one deal (one per XCD) share a segment, consecutive deals
+        // walk through a 32-entry pattern in which segment s appears seg_w[s] times (its share of the
+        // launch's work: pools x cost per pool, so that all blocks finish together), and the pattern is
+        // rotated by one every 32 deals (one pass over an XCD's 32 CUs), so every XCD -- and, as the
+        // dispatcher fills CUs in order, every CU -- hosts all families.  Placement is only a performance
+        // assumption: any placement computes the same result.
+        const int x = bidx & 7, j = bidx >> 3, q = j >> 5, p = (j + q) & 31;
+        sidx = ma.pattern[p];
+        const int w = ma.seg_w[sidx];
+        local = (q * w + ma.rank[p]) * 8 + x;
+        nblocks = (((int)gridDim.x - fb) >> 8) * w * 8;
+    } else {
+        nblocks = ((int)gridDim.x - fb) / ma.nseg;
+        sidx = bidx % ma.nseg;
+        local = bidx / ma.nseg;
+    }
     const MultiSeg& sg = ma.seg[sidx];
     SweepArgs a = ma.common;
     a.m = sg.m;

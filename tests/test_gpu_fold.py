@@ -173,3 +173,36 @@ def test_empty_segment_through_the_abi_is_ignored():
             np.testing.assert_array_equal(Dd, D)
         finally:
             be.close()
+
+
+@pytest.mark.parametrize("opts", [dict(xcd_map=0), dict(xcd_map=1), dict(wave_split=1), dict(wave_split=1, inline_fold=1)])
+@pytest.mark.parametrize("families", ["pg", "pgu", "pgup"])
+def test_fused_launch_block_maps_agree_with_oracle(opts, families):
+    """The fused multi-family launch under its block -> segment maps (plain b % nseg, XCD-aware, wavefronts
+    dealt to the families): same trades bit for bit, same Ψ to summation-order rounding."""
+    n = 200
+    batches = [synth.product_pools(300_000, n, seed=61), synth.geomean_pools(200_001, n, seed=62)]
+    if "u" in families:
+        batches.append(synth.univ3_pools(50_000, n, 5, seed=63))
+    if families == "pgup":
+        batches.append(synth.product_pools(70_000, n, seed=64))
+    v = synth.sweep_prices(n, seed=65)
+    be = cr.DeviceBackend(n, batches)
+    for k, val in opts.items():
+        be.ctx.set_option(k, val)
+    try:
+        psi, acc = be.find_arb(v)
+        D, L = be.trades()
+        psi_f, acc_f = be.eval(v)
+        Do, Lo, psi_o, acc_o = oracle_sweep(batches, n, v, nthreads=8)
+        assert rel_to_max(psi, psi_o) <= 1e-12 and abs(acc - acc_o) <= 1e-12 * abs(acc_o)
+        np.testing.assert_array_equal(psi_f, psi)
+        g0, g1 = 300_000, 500_001
+        np.testing.assert_array_equal(D[:g0], Do[:g0])
+        np.testing.assert_array_equal(L[:g0], Lo[:g0])
+        np.testing.assert_array_equal(D[g1:], Do[g1:])
+        np.testing.assert_array_equal(L[g1:], Lo[g1:])
+        scale = np.maximum(batches[1].R.max(axis=1), 1.0)[:, None]
+        assert np.max(np.abs(D[g0:g1] - Do[g0:g1]) / scale) <= 1e-12
+    finally:
+        be.close()
