@@ -150,6 +150,53 @@ def route_leg(name, batches, n):
     return out
 
 
+def single_process_main(args):
+    """N shards driven by ONE host thread / process through cfmm_ctx_create_multi (what a Julia or C caller
+    uses): every step is a host-pointer cfmm_find_arb -- v staged on every device, N sweeps launched by N
+    worker threads, the shards' {Ψ, acc} summed on the host.  PCIe-inclusive by construction."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devs) != args.gpus:
+        raise SystemExit("--devices must list --gpus ordinals")
+    desc, n, build = WORKLOADS[args.workload]
+    shards = [build(r) for r in range(args.gpus)]                  # weak scaling: one config-sized shard per device
+    batches = [cr.PoolBatch.concat([sh[k] for sh in shards]) for k in range(len(shards[0]))]
+    m_total = sum(len(b) for b in batches)
+    v = synth.sweep_prices(n, seed=1234)
+    be = cr.DeviceBackend(n, batches, device=devs)
+    for kv in args.opt:
+        k, val = kv.split("=")
+        be.ctx.set_option(k, int(val))
+    for _ in range(args.warmup):
+        be.ctx.find_arb(v)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        be.ctx.find_arb(v)
+    elapsed = time.perf_counter() - t0
+    psi = be.ctx.netflows()
+    obj = objective_for(args.workload, n)
+    v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
+    r = cr.Router(obj, batches, n, _backend=be)
+    cr.route_(r, v=v0, solver="native")
+    ts = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        cr.route_(r, v=v0, solver="native")
+        ts.append(time.perf_counter() - t1)
+    line = {"metric": "find_arb! pools/sec + route! wall-clock, 1M-pool arbitrage, 1/2/4/8 GPU",
+            "value": m_total * args.steps / elapsed, "unit": "pools/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_is": "host-pointer cfmm_find_arb calls per second x pools (PCIe-inclusive: v in, Ψ out every step)",
+            "config": {"workload": f"{args.workload}: {desc}", "pools_total": m_total, "n_tokens": n, "devices": devs,
+                       "sharding": f"single process, cfmm_ctx_create_multi over {args.gpus} shards, host-side rank-ordered sum"},
+            "route": {"native_ms": 1e3 * min(ts), "evaluations": r.info["funcalls"],
+                      "sweep_ms": 1e3 * r.info["sweep_seconds"], "max_netflow": float(np.max(np.abs(psi)))}}
+    print(json.dumps(line))
+    r.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,11 +208,21 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-cold pass")
     ap.add_argument("--rccl", action="store_true", help="force the RCCL all-reduce instead of the one-shot peer gather")
+    ap.add_argument("--cold-only", action="store_true",
+                    help="the timed region rotates over > 300 MB of market copies (pool state from HBM, not the Infinity "
+                         "Cache): used for the rocprofv3 summary of the HBM-resident figure")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process: the multi-device context of the C ABI (cfmm_ctx_create_multi), a step is "
+                         "one host-pointer cfmm_find_arb over all N shards (PCIe-inclusive)")
+    ap.add_argument("--devices", default="", help="--single-process: comma-separated HIP ordinals (default 0..N-1; an "
+                                                  "ordinal may repeat to put several shards on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process:
+        return single_process_main(args)
     if args.gpus > 1 and world == 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, rendezvous on
         # 127.0.0.1 (the container hostname may not resolve).  Same command line, re-executed under torchrun.
@@ -245,6 +302,24 @@ def main():
         _plain_step()
         n_steps_run[0] += 1
 
+    ring_ctx = None
+    if args.cold_only and not use_dist:
+        # rotate the timed steps over enough copies of the market to exceed the 256 MB Infinity Cache
+        per_copy = alg_bytes(batches, True) + 16 * sum(len(b) for b in batches if b.kind == KIND_GEOMEAN)
+        copies = int(np.ceil(320e6 / per_copy)) + 1
+        ring_ctx = [be] + [cr.DeviceBackend(n, batches, device=local_rank) for _ in range(copies - 1)]
+        for b_ in ring_ctx:
+            b_.ctx.set_stream(stream.cuda_stream)
+            for kv in args.opt:
+                k, val = kv.split("=")
+                b_.ctx.set_option(k, int(val))
+        ring_pos = [0]
+
+        def step():   # noqa: F811
+            b_ = ring_ctx[ring_pos[0] % len(ring_ctx)]
+            ring_pos[0] += 1
+            b_.ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), materialize)
+
     for _ in range(args.warmup):
         step()
 
@@ -258,6 +333,8 @@ def main():
         for _ in range(args.steps):
             step()
         ev1.record(stream)
+        while not ev1.query():   # busy-wait for the last step (a blocking wait adds its wake-up latency to K steps,
+            pass                 # which at the driver's K = 20 is ~1 us per step), then the synchronize of the contract
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0   # this rank's K steps are complete (with the collective inside every step no
         if use_dist:                    # rank finishes step k before all ranks contributed to it); the closing
@@ -269,11 +346,17 @@ def main():
     # pass 2 -- the same K steps again with a hipEvent pair attached to every kernel launch (start /
     # stop written by the command processor, hipExtLaunchKernel) for the roofline; kept out of pass 1
     # so that the timed region carries nothing but the work
-    be.ctx.set_option("time_kernels", 1)
-    be.ctx.kernel_times()  # reset
+    timed_ctxs = ring_ctx if ring_ctx else [be]
+    for b_ in timed_ctxs:
+        b_.ctx.set_option("time_kernels", 1)
+        b_.ctx.kernel_times()  # reset
     elapsed2, _ = timed_pass()
-    kt = be.ctx.kernel_times()
-    be.ctx.set_option("time_kernels", 0)
+    kt = {"sweep_ms": 0.0, "reduce_ms": 0.0}
+    for b_ in timed_ctxs:
+        kt_b = b_.ctx.kernel_times()
+        kt["sweep_ms"] += kt_b["sweep_ms"]
+        kt["reduce_ms"] += kt_b["reduce_ms"]
+        b_.ctx.set_option("time_kernels", 0)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -283,7 +366,7 @@ def main():
     # the passes above are "warm" (what a running route! sees).  Rotating over enough distinct copies
     # of the market to exceed 300 MB makes every sweep read its pool state from HBM.
     cold = None
-    if world == 1 and not use_dist and not args.no_cold:
+    if world == 1 and not use_dist and not args.no_cold and not args.cold_only:
         per_copy = alg_bytes(batches, True) + 16 * sum(len(b) for b in batches if b.kind == KIND_GEOMEAN)
         copies = int(np.ceil(320e6 / per_copy)) + 1
         extra = [cr.DeviceBackend(n, batches, device=local_rank) for _ in range(copies - 1)]
@@ -419,6 +502,32 @@ def main():
         except Exception:
             traffic = None
 
+    # Roofline of the dominant kernel (the sweep launch).  Headline = pool state resident in HBM (the cold
+    # pass, or the whole timed region with --cold-only): every working set here fits the 256 MB Infinity
+    # Cache, so the warm figure (same market every step, as inside route!) is a cache number and is reported
+    # beside it, never as `frac`.  step_frac prices the WHOLE step (sweep + fold + boundaries) the same way.
+    warm = {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "kernel_ms": sweep_ms}
+    if args.cold_only:
+        hbm, resid = dict(warm), "hbm-resident: the timed steps rotate over > 300 MB of market copies (--cold-only)"
+        warm = None
+    elif cold is not None:
+        hbm = {"achieved": cold["achieved"], "frac": cold["frac"], "kernel_ms": cold["kernel_ms"]}
+        resid = ("hbm-resident: cold pass over %d market copies (%.0f MB rotated) after the timed region; the timed "
+                 "region itself sweeps one cache-resident market (see `warm`)" % (cold["copies"], cold["bytes_rotated"] / 1e6))
+    else:
+        hbm, resid = dict(warm), "cache-warm only (no cold pass in this run: N > 1 or --no-cold)"
+    roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
+                "traffic": traffic, "kernel": "cfmm::sweep_multi / cfmm::sweep_kernel (the sweep launch of one step)",
+                "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": hbm["kernel_ms"], "residency": resid,
+                "warm": warm, "cold": cold,
+                "step_frac": bytes_per_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "reduce_kernel_ms": kt["reduce_ms"] / max(args.steps, 1),
+                "step_ms_device_events": dev_ms / args.steps,
+                "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
+                "how": "kernel_ms = mean duration of the sweep launches, from hipEvent pairs written by the command "
+                       "processor at each kernel's start and stop (hipExtLaunchKernel) on the launch stream; compare "
+                       "profiles/r02_*_kernel_stats.csv (warm: --no-cold runs; hbm-resident: --cold-only runs)"}
+
     line = {
         "metric": "find_arb! pools/sec + route! wall-clock, 1M-pool arbitrage, 1/2/4/8 GPU",
         "value": value, "unit": "pools/s",
@@ -431,19 +540,7 @@ def main():
                    "sharding": ((f"pools x{world}, fold + one-shot xGMI peer all-reduce of n_tokens+1 f64 in one launch per step"
                                  if fused_peer else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
                                 if use_dist else "single GPU, no collective")},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "cfmm::sweep_kernel (all segment launches of one step)",
-                     "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": sweep_ms,
-                     "reduce_kernel_ms": kt["reduce_ms"] / max(args.steps, 1),
-                     "residency": "warm: the same market is swept every step and fits the 256 MB Infinity Cache "
-                                  "(as inside route!); see `cold` for HBM-resident pool state",
-                     "cold": cold,
-                     "step_ms_device_events": dev_ms / args.steps,
-                     "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
-                     "how": "kernel_ms = mean duration of the sweep launches over a second K-step pass, from "
-                            "hipEvent pairs written by the command processor at each kernel's start and stop "
-                            "(hipExtLaunchKernel) on the launch stream; compare profiles/*_kernel_stats.csv"},
+        "roofline": roofline,
     }
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check
@@ -460,6 +557,9 @@ def main():
         if not args.no_cpu:
             line["cpu_baseline"], line["parity"] = cpu_baseline_leg(args.workload, batches, n, v, psi_dev, route_gpu)
         line["route"] = {k: val for k, val in route_gpu.items() if not k.startswith("_")}
+    if ring_ctx:
+        for b_ in ring_ctx[1:]:
+            b_.close()
     be.close()
     if rank == 0:
         print(json.dumps(line))

@@ -198,6 +198,25 @@ class PoolBatch:
                          liquidity=self.liquidity[o:e], γ=self.γ[lo:hi], Ai=self.Ai[lo:hi])
 
     @staticmethod
+    def concat(batches):
+        """One batch holding the pools of several same-family batches, in order."""
+        batches = list(batches)
+        kind = batches[0].kind
+        if any(b.kind != kind for b in batches):
+            raise ArgumentError("concat needs batches of one pool family")
+        cat = lambda name: np.concatenate([getattr(b, name) for b in batches])
+        if kind == KIND_PRODUCT:
+            return PoolBatch(kind, R=cat("R"), γ=cat("γ"), Ai=cat("Ai"))
+        if kind == KIND_GEOMEAN:
+            return PoolBatch(kind, R=cat("R"), w=cat("w"), γ=cat("γ"), Ai=cat("Ai"))
+        off, base = [np.zeros(1, dtype=np.int64)], 0
+        for b in batches:
+            off.append(b.tick_off[1:] + base)
+            base += int(b.tick_off[-1])
+        return PoolBatch(kind, current_price=cat("current_price"), tick_off=np.concatenate(off),
+                         lower_ticks=cat("lower_ticks"), liquidity=cat("liquidity"), γ=cat("γ"), Ai=cat("Ai"))
+
+    @staticmethod
     def from_pools(kind, pools):
         if kind == KIND_PRODUCT:
             return PoolBatch(kind, R=[p.R for p in pools], γ=[p.γ for p in pools], Ai=[p.Ai for p in pools])

@@ -59,3 +59,23 @@ def test_bench_under_torchrun_world1(extra):
     assert "error" not in rs and rs["ranks_agree_on_v"] and rs["evaluations"] >= 5
     tag = "rccl" if extra else "peer"
     json.dump(line, open(os.path.join(ROOT, "gpurun_out", f"bench_torchrun_world1_{tag}.json"), "w"), indent=1)
+
+
+def test_bench_single_process_multi_device_and_cold_only():
+    """bench.py --single-process (cfmm_ctx_create_multi, here 3 shards on the one GPU) and --cold-only."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-process", "--devices",
+                        "0,0,0", "--steps", "10", "--warmup", "2", "--workload", "config4shard"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    print(r.stdout[-1500:], r.stderr[-2000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["config"]["pools_total"] == 1_500_000
+    assert "cfmm_ctx_create_multi" in line["config"]["sharding"] and line["route"]["evaluations"] >= 5
+    json.dump(line, open(os.path.join(ROOT, "gpurun_out", "bench_single_process_3shards.json"), "w"), indent=1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "6", "--cold-only",
+                        "--no-cpu", "--workload", "product1m"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    print(r.stdout[-1500:], r.stderr[-2000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["roofline"]["residency"].startswith("hbm-resident") and line["roofline"]["warm"] is None
+    assert 0.2 < line["roofline"]["frac"] < 1.0

@@ -315,3 +315,18 @@ def test_c_abi_error_codes_without_device():
     assert L.cfmm_set_stream(None, None) == -1 and L.cfmm_find_arb(None, None) == -1
     assert L.cfmm_peer_allreduce(None, None, 1, 0, 4, 1, None) == -1
     assert b"gfx950" in L.cfmm_version()
+
+
+def test_bench_self_spawns_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment re-executes itself under
+    torch.distributed.run (127.0.0.1 rendezvous): both ranks start; with no GPU each fails loudly."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert "[bench] spawning 2 ranks" in out and "--nproc-per-node=2" in out and "127.0.0.1" in out
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert "[rank 0/2] bench.py needs an MI355X" in out and "[rank 1/2] bench.py needs an MI355X" in out
