@@ -323,34 +323,38 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    def timed_pass():
+    def timed_pass(device_events=False):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0 = ev1 = None
+        if device_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(stream)
+        if device_events:
+            ev0.record(stream)
         for _ in range(args.steps):
             step()
-        ev1.record(stream)
-        while not ev1.query():   # busy-wait for the last step (a blocking wait adds its wake-up latency to K steps,
-            pass                 # which at the driver's K = 20 is ~1 us per step), then the synchronize of the contract
+        if device_events:
+            ev1.record(stream)
+        while not stream.query():   # busy-wait for the last step (a blocking wait adds its wake-up latency to the K
+            pass                    # steps: ~1 us per step at the driver's K = 20), then the synchronize of the contract
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0   # this rank's K steps are complete (with the collective inside every step no
         if use_dist:                    # rank finishes step k before all ranks contributed to it); the closing
             dist.barrier()              # barrier follows the clock read, and the MAX over ranks is reported
-        return dt, ev0.elapsed_time(ev1)
+        return dt, (ev0.elapsed_time(ev1) if device_events else None)
 
-    # pass 1 -- THE timed region: K steps between barrier+synchronize, nothing else on the stream
-    elapsed, dev_ms = timed_pass()
-    # pass 2 -- the same K steps again with a hipEvent pair attached to every kernel launch (start /
-    # stop written by the command processor, hipExtLaunchKernel) for the roofline; kept out of pass 1
-    # so that the timed region carries nothing but the work
+    # pass 1 -- THE timed region: K steps between barrier+synchronize, nothing else on the stream or the host
+    elapsed, _ = timed_pass()
+    # pass 2 -- the same K steps again with a hipEvent pair attached to every kernel launch (start / stop written
+    # by the command processor, hipExtLaunchKernel) for the roofline, and one event pair around the K steps
+    # (device-side step time); kept out of pass 1 so that the timed region carries nothing but the work
     timed_ctxs = ring_ctx if ring_ctx else [be]
     for b_ in timed_ctxs:
         b_.ctx.set_option("time_kernels", 1)
         b_.ctx.kernel_times()  # reset
-    elapsed2, _ = timed_pass()
+    elapsed2, dev_ms = timed_pass(device_events=True)
     kt = {"sweep_ms": 0.0, "reduce_ms": 0.0}
     for b_ in timed_ctxs:
         kt_b = b_.ctx.kernel_times()
@@ -522,7 +526,6 @@ def main():
                 "warm": warm, "cold": cold,
                 "step_frac": bytes_per_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "reduce_kernel_ms": kt["reduce_ms"] / max(args.steps, 1),
-                "step_ms_device_events": dev_ms / args.steps,
                 "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
                 "how": "kernel_ms = mean duration of the sweep launches, from hipEvent pairs written by the command "
                        "processor at each kernel's start and stop (hipExtLaunchKernel) on the launch stream; compare "

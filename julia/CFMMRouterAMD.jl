@@ -2,9 +2,10 @@
 # `find_arb!` sweep and Ψ/dual reductions run in libcfmm_amd.so (include/cfmm_amd.h) while
 # LBFGSB.jl keeps driving the outer loop exactly as in CFMMRouter.jl's src/router.jl:58-108.
 #
-# STATUS: written against Julia 1.7+/CFMMRouter v0.3.1 but NOT EXECUTED -- there is no Julia
-# toolchain in the build image.  The same call sequence is exercised through the Python mirror
-# (cfmmrouter.jl_amd/router.py) and tests/test_gpu_parity.py.
+# STATUS: EXPERIMENTAL -- written against Julia 1.7+/CFMMRouter v0.3.1 but NEVER EXECUTED: there is no
+# Julia toolchain in the build image.  Every ccall below has a twin that IS executed on the MI355X:
+# the plain-C clients tests/c/abi_smoke.c and tests/c/abi_multi.c (same entry points, same argument
+# order) and the Python mirror (cfmmrouter.jl_amd/router.py, tests/test_gpu_*.py).
 #
 # Usage (drop-in for the README quick start):
 #     using CFMMRouter, CFMMRouterAMD
@@ -15,7 +16,7 @@ module CFMMRouterAMD
 using CFMMRouter
 using CFMMRouter: CFMM, ProductTwoCoin, GeometricMeanTwoCoin, UniV3, Objective
 using LBFGSB
-import CFMMRouter: route!, netflows, netflows!, find_arb!
+import CFMMRouter: route!, netflows, netflows!, find_arb!, update_reserves!
 
 export AMDRouter, route_native!
 
@@ -47,9 +48,18 @@ mutable struct AMDRouter{O,T}
 end
 
 # Router(objective, cfmms, n_tokens) -- src/router.jl:18-36
-function AMDRouter(objective::O, cfmms::Vector{C}, n_tokens; device::Integer=0) where {O<:Objective,C<:CFMM{Float64}}
+# `device` is a HIP ordinal, or a vector of ordinals: the pools are then split in contiguous blocks over
+# those GPUs from this one Julia task (cfmm_ctx_create_multi: one L-BFGS-B drives all shards, the
+# shards' Ψ are summed on the host in device order; no MPI, no RCCL, nothing else to set up).
+function AMDRouter(objective::O, cfmms::Vector{C}, n_tokens; device=0) where {O<:Objective,C<:CFMM{Float64}}
     ctxref = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:cfmm_ctx_create, LIB), Cint, (Cint, Int32, Ref{Ptr{Cvoid}}), device, n_tokens, ctxref)
+    rc = if device isa Integer
+        ccall((:cfmm_ctx_create, LIB), Cint, (Cint, Int32, Ref{Ptr{Cvoid}}), device, n_tokens, ctxref)
+    else
+        ids = Int32.(collect(device))
+        GC.@preserve ids ccall((:cfmm_ctx_create_multi, LIB), Cint, (Int32, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
+                               length(ids), ids, n_tokens, ctxref)
+    end
     check(Ptr{Cvoid}(C_NULL), rc)
     ctx = ctxref[]
     order = Int[]
@@ -154,6 +164,38 @@ function route!(r::AMDRouter; v=nothing, verbose=false, m=5, factr=1e1, pgtol=1e
                         maxfun=maxfun, maxiter=maxiter)
     r.v .= vopt
     find_arb!(r, vopt)                                          # src/router.jl:107
+end
+
+# update_reserves!(r) -- src/router.jl:127-132 (upstream calls a per-pool method that exists nowhere).  Here:
+# the pools move to R + γΔ − Λ (src/cfmms.jl:26-31) in place on the device, from the trades of the latest
+# find_arb!/route!; UniV3 pools move to the price the arbitrage left them at.  The host-side pool objects
+# are refreshed from the device (16 bytes per two-coin pool, 8 per UniV3 pool); `sync=false` skips that.
+function update_reserves!(r::AMDRouter; sync::Bool=true)
+    check(r.ctx, ccall((:cfmm_update_reserves, LIB), Cint, (Ptr{Cvoid},), r.ctx))
+    if sync
+        seg, pos = Int32(0), 0
+        for T in (ProductTwoCoin, GeometricMeanTwoCoin, UniV3)
+            idx = [i for i in r.order[pos+1:end] if r.cfmms[i] isa T]   # r.order is grouped by family
+            isempty(idx) && continue
+            if T === UniV3
+                p = Vector{Float64}(undef, length(idx))
+                GC.@preserve p check(r.ctx, ccall((:cfmm_get_prices, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), r.ctx, seg, p))
+                for (k, i) in enumerate(idx)
+                    c = r.cfmms[i]
+                    r.cfmms[i] = UniV3(p[k], c.lower_ticks, c.liquidity, c.γ, c.Ai)   # re-derives current_tick (:235)
+                end
+            else
+                R = Matrix{Float64}(undef, 2, length(idx))
+                GC.@preserve R check(r.ctx, ccall((:cfmm_get_reserves, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), r.ctx, seg, R))
+                for (k, i) in enumerate(idx)
+                    r.cfmms[i].R .= @view R[:, k]
+                end
+            end
+            seg += Int32(1); pos += length(idx)
+        end
+    end
+    foreach(d -> fill!(d, 0), r.Δs); foreach(l -> fill!(l, 0), r.Λs)
+    return nothing
 end
 
 # Optional fast path: the whole of route! inside the library (cfmm_route: its own L-BFGS-B, the

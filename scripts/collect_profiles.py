@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -14,12 +14,17 @@ for d in glob.glob(os.path.join(src, "prof_*")):
     if not os.path.isdir(d):
         continue
     w = os.path.basename(d)[5:]
-    for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{rnd}_{w}_kernel_stats.csv"))
 for f in glob.glob(os.path.join(src, "tune_*.txt")):
     shutil.copy(f, os.path.join(dst, f"{rnd}_{os.path.basename(f)}"))
 if os.path.exists(os.path.join(src, "traffic.json")):
     shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, "traffic.json"))
+for name in ("floor.txt", "dist_world1.json", "bench_torchrun_world1_peer.json", "bench_torchrun_world1_rccl.json",
+             "bench_single_process_3shards.json", "pytest_gpu.log", "smoke.log"):
+    if os.path.exists(os.path.join(src, name)):
+        out = {"floor.txt": "launch_floor.txt"}.get(name, name)
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{out}"))
 for f in glob.glob(os.path.join(src, "benchfull_*.log")):
     lines = [x for x in open(f) if x.startswith("{")]
     if lines:
@@ -28,7 +33,7 @@ for f in glob.glob(os.path.join(src, "benchfull_*.log")):
 for w in {os.path.basename(d).split("_")[1] for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)}:
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = glob.glob(os.path.join(src, f"pmc_{w}_{c}", "*counter_collection.csv"))
+        files = glob.glob(os.path.join(src, f"pmc_{w}_{c}", "**", "*counter_collection.csv"), recursive=True)
         acc = {}
         for f in files:
             for row in csv.DictReader(open(f)):

@@ -82,6 +82,25 @@ int main()
         hipFree(a);
         hipFree(b);
     }
+    // HBM-resident copy: rotate over 6 buffer pairs of 72 MB (432 MB > the 256 MB Infinity Cache)
+    {
+        const long n = (long)(72e6 / 2 / 16);
+        double2 *a[6], *b[6];
+        for (int k = 0; k < 6; ++k) { hipMalloc(&a[k], n * 16); hipMalloc(&b[k], n * 16); hipMemset(a[k], 1, n * 16); }
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        double tot = 0;
+        for (int i = 0; i < 66; ++i) {
+            hipExtLaunchKernelGGL(copy_k, dim3(1024), dim3(256), 0, s, e0, e1, 0, a[i % 6], b[i % 6], n);
+            hipStreamSynchronize(s);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (i >= 6) tot += ms;
+        }
+        printf("copy  72.0 MB HBM-resident (6 rotating buffer pairs): %6.2f us = %5.2f TB/s\n", 1e3 * tot / 60, 72.0 / (1e3 * tot / 60));
+        for (int k = 0; k < 6; ++k) { hipFree(a[k]); hipFree(b[k]); }
+    }
     // dependent pair per step, wall clock over 200 steps (what a sweep + fold step pays in boundaries)
     {
         hipDeviceSynchronize();
