@@ -410,6 +410,9 @@ int ensure_geometry(cfmm_ctx* c)
         s.trade_off = trades;
         trades += s.m;
         fusable = fusable && s.unroll == 1;
+        // the fused kernel always carries the wavefront-cooperative UniV3 walk; "univ3_coop" = 0 (lane-per-pool
+        // walks only) is honoured by sweeping such routers with per-segment launches
+        if (s.kind == CFMM_KIND_UNIV3 && c->opt_univ3_coop == 0) fusable = false;
         any_big = any_big || s.block != kSmallBlock;
     }
     c->groups.clear();
@@ -1184,7 +1187,7 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
             if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
         }
     if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
-        slot == &c->opt_geomean_exact || slot == &c->opt_xcd_map || slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
+        slot == &c->opt_geomean_exact || slot == &c->opt_univ3_coop || slot == &c->opt_xcd_map || slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
         c->geometry_dirty = true;
     return CFMM_OK;
 }

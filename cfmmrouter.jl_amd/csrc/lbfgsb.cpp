@@ -596,7 +596,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             dnorm2 += d[i] * d[i];
             gd += g[i] * d[i];
         }
-        bool ls_failed = false;
+        bool ls_failed = false, noise_floor = false;
         if (!(gd < 0.0)) {
             ls_failed = true; // not a descent direction
         }
@@ -642,6 +642,15 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                     res.iterations = iter;
                     return res;
                 }
+                if (opt.stop_in_noise && fnew >= f_old &&
+                    fnew - f_old <= opt.factr * kEps * std::max({std::fabs(f_old), std::fabs(fnew), 1.0})) {
+                    // no decrease left beyond rounding noise (see LbfgsbOptions::stop_in_noise): keep the iterate
+                    for (int i = 0; i < n; ++i) x[i] = x_old[i];
+                    g = g_old;
+                    f = f_old;
+                    noise_floor = true;
+                    break;
+                }
                 double gdn = 0.0;
                 for (int i = 0; i < n; ++i) gdn += g[i] * d[i];
                 f = fnew;
@@ -651,6 +660,11 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                     ls_failed = res.evaluations < opt.maxfun;
                     break;
                 }
+            }
+            if (noise_floor) {
+                res.status = 1;
+                res.message = "CONVERGENCE: RELATIVE REDUCTION OF F <= FACTR*EPSMCH (trial point within rounding noise)";
+                break;
             }
             if (!ls_failed && task == MoreThuente::kError) ls_failed = true;
             if (ls_failed) { // restore the last iterate

@@ -33,6 +33,14 @@ struct LbfgsbOptions {
     // nbd = 2 with an infinite upper bound (src/router.jl:67-70), i.e. it runs boxed; SciPy maps
     // an infinite bound to "no bound" and therefore does not.  true = the reference's behaviour.
     bool boxed_from_nbd = false;
+    // At convergence the objective sits on its rounding-noise floor (route!'s factr = 1e1 asks for a relative
+    // decrease of 10 eps, while the dual value is a sum over 10^6 pools): a trial point then returns f one ulp
+    // ABOVE the current one, Moré-Thuente rejects it, and the line search burns up to max_linesearch
+    // evaluations shrinking the step among values that differ in the last bit (observed: 14 vs 24
+    // evaluations of config3 depending on nothing but the summation order of Ψ).  true: a trial point that
+    // does not decrease f, but differs from it by no more than the factr tolerance itself, ends the run with
+    // the current iterate -- the same stopping test, applied before the step is shrunk instead of after.
+    bool stop_in_noise = true;
 };
 
 struct LbfgsbResult {

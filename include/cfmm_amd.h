@@ -165,7 +165,10 @@ int cfmm_dual_value(cfmm_ctx* ctx, double* acc);
 
 /* ---- device-resident variants (stream / RCCL interop; no host round trip) -------------- */
 
-/* d_v: n_tokens device doubles.  d_out: n_tokens+1 device doubles = {psi..., acc}: the
+/* d_v: n_tokens device doubles (must be finite and > 0, src/cfmms.jl:129: the library cannot validate device
+ * memory -- a NaN price propagates into the trades and psi of every pool that touches the token, exactly
+ * as the reference's arithmetic does; non-positive prices give undefined trades).
+ * d_out: n_tokens+1 device doubles = {psi..., acc}: the
  * buffer a sharded run all-reduces (one collective per evaluation).  Asynchronous on the
  * context's stream.  materialize != 0: also write Delta/Lambda (find_arb! semantics). */
 int cfmm_sweep_dev(cfmm_ctx* ctx, const double* d_v, double* d_out, int materialize);
