@@ -41,7 +41,7 @@ struct Segment {
     double2* R = nullptr;
     double2* w = nullptr;
     double* eta = nullptr;   // geomean: η = w1/w2
-    double2* lR = nullptr;   // geomean: {log R1, log R2}
+    double2* lR = nullptr;   // geomean: {Q1, Q2}, the v-independent constants of the log-space exponents (GeoMeanLogOps)
     double* gamma = nullptr;
     int2* Ai = nullptr;
     double2* pg = nullptr;
@@ -357,7 +357,7 @@ int bin_copies(const cfmm_ctx* c, int block)
     if (global_bins(c)) return 1;
     const int waves = block / 64;
     if (c->opt_bin_copies == 1) return 1;
-    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block);
+    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block, 1);   // incl. the log-price row GeometricMean launches stage
     if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
     // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
     return per_wave <= (block == kBigBlock ? 80 : (block == kMidBlock ? 48 : 32)) * 1024 ? waves : 1;
@@ -514,6 +514,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.v = d_v;
         a.n = c->n;
         a.n_pad = c->n_pad;
+        a.need_logv = 0;
+        if (!gb && c->opt_geomean_exact == 0)
+            for (int k = 0; k < g.nseg; ++k)
+                if (c->segs[(size_t)g.first + k].kind == CFMM_KIND_GEOMEAN) a.need_logv = 1;
         a.copies = bin_copies(c, g.block);
         a.m = 0;
         a.Delta = a.Lambda = nullptr;
@@ -525,7 +529,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.fold_out = d_out;
         a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
         a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
-        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block);
+        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
             ea = take_event(c);
@@ -1240,8 +1244,10 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
     std::vector<double2> lR((size_t)m);
     std::vector<double> etas((size_t)m);
     for (int64_t i = 0; i < m; ++i) {
-        etas[(size_t)i] = w[2 * i] / w[2 * i + 1]; // src/cfmms.jl:188
-        lR[(size_t)i] = make_double2(std::log(R[2 * i]), std::log(R[2 * i + 1]));
+        const double e = w[2 * i] / w[2 * i + 1]; // src/cfmms.jl:188
+        const double lg = std::log(gamma[i]), le = std::log(e), l1 = std::log(R[2 * i]), l2 = std::log(R[2 * i + 1]);
+        etas[(size_t)i] = e;
+        lR[(size_t)i] = make_double2(((lg + le) + l2) + e * l1, e * ((lg + l1) - le) + l2);   // {Q1, Q2}
     }
     HIP_TRY(c, hipSetDevice(c->device));
     Segment s;
@@ -1416,7 +1422,7 @@ int cfmm_update_reserves(cfmm_ctx* c)
     for (Segment& s : c->segs) {
         if (s.kind != CFMM_KIND_UNIV3) {   // R <- R + γΔ − Λ on the device, no host traffic
             hipError_t e = launch_update_two_coin(s.R, s.gamma, c->d_delta + s.trade_off, c->d_lambda + s.trade_off,
-                                                  s.kind == CFMM_KIND_GEOMEAN ? s.lR : nullptr, s.m, c->stream);
+                                                  s.kind == CFMM_KIND_GEOMEAN ? s.lR : nullptr, s.eta, s.m, c->stream);
             if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "update launch failed: %s", hipGetErrorString(e));
             continue;
         }

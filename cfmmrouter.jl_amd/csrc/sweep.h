@@ -28,7 +28,8 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double* gamma;
     const int2* Ai;
     const double* eta;           // [m] η = w1/w2                  prepared at upload
-    const double2* lR;           // [m] {log R1, log R2}          prepared at upload
+    const double2* Q;            // [m] {Q1, Q2}: the v-independent part of the two log-space exponents, prepared at
+                                 //     upload: Q1 = log γ + log η + log R2 + η·log R1,  Q2 = η·(log γ + log R1 − log η) + log R2
     int reference_order;         // 1: evaluate with pow in the reference's operation order
 };
 struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
@@ -49,6 +50,7 @@ struct SweepArgs {
     const double* v;             // [n] device
     int n;                       // n_tokens
     int n_pad;                   // n rounded up to even (LDS row pitch)
+    int need_logv;               // 1: also stage log v per token in LDS (launches with a log-space GeometricMean segment)
     int copies;                  // private bin copies per block (1 or one per wavefront)
     int64_t m;                   // pools in this segment
     double2* Delta;              // [m] segment base, may be null when !materialize
@@ -150,11 +152,11 @@ struct PeerSet {
 hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                                 const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
-// R <- (R + gamma*Delta) - Lambda in place; lR (nullable) <- {log R1, log R2}
+// R <- (R + gamma*Delta) - Lambda in place; GeometricMean (Q, eta non-null): Q <- the exponents' constants for the new R
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  double2* lR, int64_t m, hipStream_t s);
+                                  double2* Q, const double* eta, int64_t m, hipStream_t s);
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block);
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv = 0);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 
 } // namespace cfmm

@@ -51,6 +51,7 @@ __device__ __forceinline__ double max0(double x)
 // ---------------------------------------------------------------------------------------------
 struct ProductOps {
     static constexpr bool kWaveCooperative = false;
+    static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 R;
         double g;
@@ -120,6 +121,7 @@ __device__ __forceinline__ double geom_arb_lambda(double m, double r1, double r2
 
 struct GeoMeanOps {
     static constexpr bool kWaveCooperative = false;
+    static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 R, w;
         double g;
@@ -161,31 +163,36 @@ struct GeoMeanOps {
 
 // Log-space evaluation of the same two closed forms (default for GeometricMeanTwoCoin).
 // With c = γ·m·e·r_a (the pow-free factor of :180), l_x = log x:
-//     (c·r_b^e)^(1/(e+1))                    = exp((l_c + e·l_b) / (e+1))
-//     ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = exp((l_a + e·(l_b − l_c + l_a)) / (1+e))
-// Everything that does not depend on v and is worth its bytes is prepared once at upload
-// (cfmm_abi.hip): η = w₁/w₂, log R₁, log R₂ (1/(η+1) is recomputed: a division is cheaper than 8 B).  Direction 2 uses e = 1/η, for which the two exponents become
-// (η·l_c + l_b)/(η+1) and (η·l_a + (l_b − l_c) + l_a)/(η+1).  The second form is not evaluated at all:
-// the two new reserves stand in the ratio c/r_a fixed by the market price, so it equals the first
-// result times r_a/c.  Per trading pool that leaves 1 log + 1 exp + 4 divisions instead of 4 pow + 6
-// divisions; pools inside the no-arbitrage band cost two multiplies and a compare.
-// The exponent carries an absolute rounding error of a few 1e-16·max(1, η·|l|)/(η+1), so trades
-// agree with the reference-order forms to ~1e-15 of the reserve scale (asserted at 1e-12 in
-// tests/test_gpu_parity.py); unlike r2^η in the reference, nothing here can overflow.
+//     X = (c·r_b^e)^(1/(e+1))                    = exp((l_c + e·l_b) / (e+1))      the tendered side's new reserve
+//     Y = ((r_b·r_a^(1/e)) / (e·γ·m))^(e/(1+e))  = X·r_a/c                          the received side's new reserve
+// (the second identity: at the optimum the pool's marginal price equals the fee-adjusted market
+// price, which fixes the RATIO of the two new reserves).  Nothing per-pool is left inside a
+// logarithm: l_c = log γ + log e + log r_a + (log v_out − log v_in), so with log v staged per TOKEN
+// in LDS once per block (stage_prices) and the v-independent sums prepared per POOL at upload
+//     direction 1 (e = η):    exponent = (Q1 + Δ) / (η+1),       Q1 = log γ + log η + log R2 + η·log R1
+//     direction 2 (e = 1/η):  exponent = (Q2 − η·Δ) / (η+1),     Q2 = η·(log γ + log R1 − log η) + log R2
+// with Δ = log v2 − log v1.  Per trading pool that leaves 1 exp + 3 divisions (the exponent, Y and
+// the final /γ) instead of 4 pow + 6 divisions (round 1: 1 log + 2 exp + 3 div); pools inside the
+// no-arbitrage band cost four multiplies and two compares.  The exponent carries an absolute rounding
+// error of a few 1e-16·max(1, η·|l|)/(η+1), so trades agree with the reference-order forms to ~1e-15 of
+// the reserve scale (asserted at 1e-12 in tests/test_gpu_parity.py); unlike r2^η in the reference,
+// nothing here can overflow.
 struct GeoMeanLogOps {
     static constexpr bool kWaveCooperative = false;
+    static constexpr bool kNeedsLogPrices = true;
     struct Raw {
-        double2 R, lR;
+        double2 R, Q;
         double eta, g;
         int2 ai;
     };
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        return Raw{p.R[i], p.lR[i], p.eta[i], p.gamma[i], p.Ai[i]};
+        return Raw{p.R[i], p.Q[i], p.eta[i], p.gamma[i], p.Ai[i]};
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    // dlv = log v2 − log v1
+    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, double dlv, Trade& t) const
     {
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double eta = r.eta;                     // η = w₁/w₂, prepared at upload
@@ -201,17 +208,10 @@ struct GeoMeanLogOps {
         for (int pass = 0; pass < 2; ++pass) {
             const bool dir1 = pass == 0 && p1;
             if (pass == 0 ? !(p1 || p2) : !(p1 && p2)) break;
-            const double c = (dir1 ? n1 : n2) / (dir1 ? d1 : d2);
-            const double lc = log(c);
             const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
-            const double lb = dir1 ? r.lR.x : r.lR.y;
-            const double A = dir1 ? (lc + eta * lb) : (eta * lc + lb);
+            const double A = dir1 ? (r.Q.x + dlv) : (r.Q.y - eta * dlv);
             const double X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
-            // the received side's reserve after the trade is X·r_a/c: at the optimum the pool's marginal
-            // price equals the (fee-adjusted) market price, which fixes the RATIO of the new reserves --
-            // ((r_b·r_a^(1/e))/(e·γ·m))^(e/(1+e)) = X·r_a/c identically -- so the second exp of the
-            // log-space form is one division
-            const double Y = X * (ra / c);
+            const double Y = ((X * ra) * (dir1 ? d1 : d2)) / (dir1 ? n1 : n2);   // X·r_a/c, c = n/d
             const double d = max0(X - rb) / g;
             const double l = max0(ra - Y);
             if (dir1) { t.d1 = d; t.l2 = l; }
@@ -237,6 +237,7 @@ struct GeoMeanLogOps {
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
     static constexpr bool kWaveCooperative = false;
+    static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 pg, ca, cb;
         double cc;
@@ -460,6 +461,7 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 // shared copy) and one slot per wavefront for the dual-scalar fold.
 struct SweepLds {
     double* v_lds;     // [n_pad]
+    double* lv_lds;    // [n_pad] log v (only when a.need_logv)
     double* bins;      // [copies][n_pad]
     double* wsum;      // [kWaves]
     double* my_bins;   // this wavefront's copy
@@ -471,7 +473,8 @@ __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
     extern __shared__ double lds[];
     SweepLds L;
     L.v_lds = lds;
-    L.bins = lds + (GBINS ? 0 : a.n_pad);
+    L.lv_lds = lds + a.n_pad;
+    L.bins = lds + (GBINS ? 0 : (a.need_logv ? 2 : 1) * a.n_pad);
     L.wsum = GBINS ? lds : L.bins + (size_t)a.copies * a.n_pad;
     L.my_bins = L.bins + (size_t)(a.copies == 1 ? 0 : (threadIdx.x >> 6)) * a.n_pad;
     return L;
@@ -484,7 +487,12 @@ __device__ __forceinline__ void stage_prices(const SweepArgs& a, const SweepLds&
     const int tid = threadIdx.x;
     const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
     const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
-    for (int j = tid; j < n_stage; j += BLOCK) L.v_lds[j] = a.v[j];
+    const bool logs = !GBINS && a.need_logv;
+    for (int j = tid; j < n_stage; j += BLOCK) {
+        const double vj = a.v[j];
+        L.v_lds[j] = vj;
+        if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
+    }
     for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
     __syncthreads();
 }
@@ -508,8 +516,16 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         if constexpr (GBINS) { v1 = a.v[tok.x]; v2 = a.v[tok.y]; }
         else { v1 = L.v_lds[tok.x]; v2 = L.v_lds[tok.y]; }
         Trade t;
-        if constexpr (Ops::kWaveCooperative) ops.solve_wave(raw, valid, v1, v2, t);
-        else ops.solve(raw, v1, v2, t);
+        if constexpr (Ops::kWaveCooperative) {
+            ops.solve_wave(raw, valid, v1, v2, t);
+        } else if constexpr (Ops::kNeedsLogPrices) {
+            double dlv;
+            if constexpr (GBINS) dlv = log(v2 / v1);     // large markets: v is not staged, one logarithm per pool
+            else dlv = L.lv_lds[tok.y] - L.lv_lds[tok.x];
+            ops.solve(raw, v1, v2, dlv, t);
+        } else {
+            ops.solve(raw, v1, v2, t);
+        }
         if (!valid) return;
         if (MAT) {
             store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
@@ -995,10 +1011,10 @@ static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEve
     else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
 }
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block)
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv)
 {
     // the fold blocks of the same launch need [block/64][kReduceCols] doubles + one flag word
-    const size_t sweep = (size_t)n_pad * (1 + copies) + block / 64;
+    const size_t sweep = (size_t)n_pad * ((need_logv ? 2 : 1) + copies) + block / 64;
     const size_t fold = (size_t)(block / 64) * kReduceCols + 2;
     return (sweep > fold ? sweep : fold) * sizeof(double);
 }
@@ -1129,11 +1145,12 @@ hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, 
 
 // update_reserves!(r) for the two-coin families -- src/router.jl:127-132 with the update the routing
 // problem prescribes (find_arb! docstring, src/cfmms.jl:26-31): R <- (R + γΔ) − Λ, in place, from
-// the trades of the latest materialising sweep; GeometricMean segments refresh {log R₁, log R₂}.
+// the trades of the latest materialising sweep; GeometricMean segments refresh the exponents'
+// v-independent constants {Q1, Q2} (see GeoMeanLogOps) with the same expressions as the upload.
 __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, const double* __restrict__ gamma,
                                                        const double2* __restrict__ Delta,
-                                                       const double2* __restrict__ Lambda, double2* __restrict__ lR,
-                                                       long long m)
+                                                       const double2* __restrict__ Lambda, double2* __restrict__ Q,
+                                                       const double* __restrict__ eta, long long m)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
@@ -1141,15 +1158,18 @@ __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, 
     const double2 r = R[i], d = Delta[i], l = Lambda[i];
     const double2 rn = make_double2((r.x + g * d.x) - l.x, (r.y + g * d.y) - l.y);
     R[i] = rn;
-    if (lR) lR[i] = make_double2(log(rn.x), log(rn.y));
+    if (Q) {
+        const double e = eta[i], lg = log(g), le = log(e), l1 = log(rn.x), l2 = log(rn.y);
+        Q[i] = make_double2(((lg + le) + l2) + e * l1, e * ((lg + l1) - le) + l2);
+    }
 }
 
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  double2* lR, int64_t m, hipStream_t s)
+                                  double2* Q, const double* eta, int64_t m, hipStream_t s)
 {
     if (m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, lR,
-                       (long long)m);
+    hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, Q,
+                       eta, (long long)m);
     return hipGetLastError();
 }
 

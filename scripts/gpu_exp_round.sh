@@ -1,3 +1,4 @@
-mkdir -p gpurun_out; rm -f gpurun_out/exp_xcd.txt
-timeout 600 python -m pytest tests/test_gpu_fold.py -m gpu -x -q -k "block_maps" 2>&1 | tail -5
-timeout 300 python scripts/exp.py config3 "xcd_map=0" "xcd_map=2" "cost_geomean=14" "cost_geomean=18" "cost_geomean=22" "cost_geomean=26" "cost_geomean=30" "cost_geomean=40" "cost_geomean=22,max_grid=768" "cost_geomean=22,max_grid=1024" 2>&1 | grep -v "amdgpu.ids" | tee -a gpurun_out/exp_xcd.txt
+mkdir -p gpurun_out; rm -f gpurun_out/exp_dbg2.txt
+for lib in libcfmm_amd.so libcfmm_dbg1.so libcfmm_dbg2.so libcfmm_dbg3.so libcfmm_dbg4.so libcfmm_dbg7.so; do
+CFMM_AMD_LIB=$PWD/cfmmrouter.jl_amd/$lib timeout 300 python scripts/exp.py config3 "" 2>&1 | grep -v "amdgpu.ids\|^#" | sed "s/^/$lib /" | tee -a gpurun_out/exp_dbg2.txt
+done
