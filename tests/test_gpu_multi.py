@@ -4,6 +4,7 @@ stores, N streams and N host worker threads run on one MI355X -- everything but 
 placement is what an 8-GPU node executes."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -122,3 +123,17 @@ def test_multi_context_rejects_device_pointer_calls():
             cr.DeviceBackend(8, [], device=[0, 99])
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_gather_protocol_with_several_ranks_on_one_gpu(world):
+    """The sharded fold + all-reduce launch (cfmm_set_peers, reduce_gather) at world > 1 on ONE GPU
+    (tests/peer_ranks_worker.py): every "rank" is a context with its own stream and shard; ranks wait for
+    each other's granules exactly as over xGMI.  Run in a subprocess with one hardware queue per rank
+    (GPU_MAX_HW_QUEUES): ranks that shared a queue would serialise behind each other's waiting launch --
+    an artefact of emulating several GPUs on one, not of the protocol."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(2 * world), CFMM_AMD_PEER_TIMEOUT_S="10")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "peer_ranks_worker.py"), str(world)],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and f"PEER_RANKS_OK world={world}" in r.stdout
