@@ -172,43 +172,58 @@ struct MoreThuente {
     }
 };
 
+// ---- vector kernels -----------------------------------------------------------------------------
+// n is a few hundred and every iteration makes ~40 passes over length-n vectors: these loops are the
+// solver's cost.  Reassociation is allowed inside the dot products only (so that they vectorise);
+// nothing here feeds the bit-exact pool arithmetic.
+inline double dotn(const double* a, const double* b, int n)
+{
+#pragma clang fp reassociate(on)
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+inline void axpyn(double alpha, const double* x, double* y, int n)
+{
+    for (int i = 0; i < n; ++i) y[i] += alpha * x[i];
+}
+
 // ---- limited-memory matrices --------------------------------------------------------------------
-// Storage is laid out for the per-iteration hot loops (n = a few hundred, m = 5): S and Y are kept
-// TRANSPOSED, Yt[i][j] = (y_j)_i with row pitch m, so that row i of W = [Y θS] -- what the Cauchy
-// search and the subspace step touch per variable -- is two short contiguous runs.
+// S and Y are stored by COLUMN (one correction pair = two contiguous length-n vectors) in a circular
+// buffer of m slots, so that W'x (dot products) and W·c (axpys) are contiguous, vectorisable passes
+// and dropping the oldest pair moves nothing.  Logical column j (oldest first) lives in slot (start+j) % m.
 struct Memory {
-    int n = 0, m = 0, col = 0;
+    int n = 0, m = 0, col = 0, start = 0;
     double theta = 1.0;
-    std::vector<double> St, Yt;            // n×m row-major, columns [0, col) valid, oldest first
-    std::vector<double> SY, SS, YY;        // m×m, row-major, [i][j] = s_i'y_j / s_i's_j / y_i'y_j (valid for i,j < col)
-    std::vector<double> M;                 // (2col)×(2col) = K^{-1}, K = [[-D, L'],[L, θ S'S]]
+    std::vector<double> Sc, Yc;            // [m][n]
+    std::vector<double> SY, SS, YY;        // m×m, row-major, logical order: [i][j] = s_i'y_j / s_i's_j / y_i'y_j
+    std::vector<double> M;                 // (2col)×(2col) = K^{-1}, K = [[-D, L'],[L, θ S'S]]  (symmetric)
     std::vector<double> K;                 // scratch
 
     void init(int n_, int m_)
     {
         n = n_;
         m = m_;
-        St.assign((size_t)n * m, 0.0);
-        Yt.assign((size_t)n * m, 0.0);
+        Sc.assign((size_t)n * m, 0.0);
+        Yc.assign((size_t)n * m, 0.0);
         SY.assign((size_t)m * m, 0.0);
         SS.assign((size_t)m * m, 0.0);
         YY.assign((size_t)m * m, 0.0);
     }
+    const double* Scol(int j) const { return &Sc[(size_t)((start + j) % m) * n]; }
+    const double* Ycol(int j) const { return &Yc[(size_t)((start + j) % m) * n]; }
 
     void reset()
     {
         col = 0;
+        start = 0;
         theta = 1.0;
     }
 
     void push(const std::vector<double>& s, const std::vector<double>& y, double sy, double yy)
     {
-        if (col == m) { // drop the oldest pair: shift the columns left by one
-            for (int i = 0; i < n; ++i) {
-                double* sr = &St[(size_t)i * m];
-                double* yr = &Yt[(size_t)i * m];
-                for (int j = 0; j + 1 < m; ++j) { sr[j] = sr[j + 1]; yr[j] = yr[j + 1]; }
-            }
+        if (col == m) { // drop the oldest pair: advance the ring, shift the small m×m tables
+            start = (start + 1) % m;
             for (int i = 0; i + 1 < m; ++i)
                 for (int j = 0; j + 1 < m; ++j) {
                     SY[i * m + j] = SY[(i + 1) * m + j + 1];
@@ -218,35 +233,19 @@ struct Memory {
             --col;
         }
         const int k = col;
-        double sS[16], sY[16], yS[16], yY[16];   // inner products of the new pair with the stored ones (m <= 16 here)
-        std::vector<double> big;
-        double *dsS = sS, *dsY = sY, *dyS = yS, *dyY = yY;
-        if (m > 16) { big.assign((size_t)4 * m, 0.0); dsS = big.data(); dsY = dsS + m; dyS = dsY + m; dyY = dyS + m; }
-        for (int j = 0; j < k; ++j) dsS[j] = dsY[j] = dyS[j] = dyY[j] = 0.0;
-        for (int i = 0; i < n; ++i) {
-            double* sr = &St[(size_t)i * m];
-            double* yr = &Yt[(size_t)i * m];
-            const double si = s[i], yi = y[i];
-            for (int j = 0; j < k; ++j) {
-                dsS[j] += si * sr[j];
-                dsY[j] += si * yr[j];
-                dyS[j] += yi * sr[j];
-                dyY[j] += yi * yr[j];
-            }
-            sr[k] = si;
-            yr[k] = yi;
-        }
-        double ss = 0.0;
-        for (int i = 0; i < n; ++i) ss += s[i] * s[i];
         for (int j = 0; j < k; ++j) {
-            SY[j * m + k] = dyS[j];          // s_j'y_new
-            SY[k * m + j] = dsY[j];          // s_new'y_j
-            SS[j * m + k] = SS[k * m + j] = dsS[j];
-            YY[j * m + k] = YY[k * m + j] = dyY[j];
+            const double* sj = Scol(j);
+            const double* yj = Ycol(j);
+            SY[j * m + k] = dotn(sj, y.data(), n);          // s_j'y_new
+            SY[k * m + j] = dotn(s.data(), yj, n);          // s_new'y_j
+            SS[j * m + k] = SS[k * m + j] = dotn(sj, s.data(), n);
+            YY[j * m + k] = YY[k * m + j] = dotn(yj, y.data(), n);
         }
         SY[k * m + k] = sy;
-        SS[k * m + k] = ss;
+        SS[k * m + k] = dotn(s.data(), s.data(), n);
         YY[k * m + k] = yy;
+        std::copy(s.begin(), s.end(), Sc.begin() + (size_t)((start + k) % m) * n);
+        std::copy(y.begin(), y.end(), Yc.begin() + (size_t)((start + k) % m) * n);
         ++col;
         theta = yy / sy;
         form_M();
@@ -274,11 +273,25 @@ struct Memory {
     // row b of W = [Y θS]
     void w_row(int b, double* w) const
     {
-        const double* yr = &Yt[(size_t)b * m];
-        const double* sr = &St[(size_t)b * m];
         for (int j = 0; j < col; ++j) {
-            w[j] = yr[j];
-            w[col + j] = theta * sr[j];
+            w[j] = Ycol(j)[b];
+            w[col + j] = theta * Scol(j)[b];
+        }
+    }
+    // out = W'x for a length-n vector x (2col entries)
+    void Wt_times(const double* x, double* out) const
+    {
+        for (int j = 0; j < col; ++j) {
+            out[j] = dotn(Ycol(j), x, n);
+            out[col + j] = theta * dotn(Scol(j), x, n);
+        }
+    }
+    // y += W·c for 2col coefficients c
+    void W_times_add(const double* c, double* y) const
+    {
+        for (int j = 0; j < col; ++j) {
+            axpyn(c[j], Ycol(j), y, n);
+            axpyn(theta * c[col + j], Scol(j), y, n);
         }
     }
     // W'W = [[Y'Y, θ Y'S], [θ S'Y, θ² S'S]]  (2col × 2col, row-major)
@@ -355,7 +368,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
 
     std::vector<double> g(n), g_old(n), x_old(n), xcp(n), z(n), d(n), t(n), s(n), y(n);
     std::vector<double> p, c, wb, v1, v2, Mc;
-    std::vector<double> r, du, wzr, WZ, vv, N;   // subspace-step scratch, reused across iterations
+    std::vector<double> rfull, wvfull, masked, du, wzr, WZ, vv, N;   // subspace-step scratch, reused across iterations
     std::vector<int> order, fixed(n), free_idx;
     order.reserve(n);
     free_idx.reserve(n);
@@ -421,17 +434,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             // (the Fortran's hpsolb) instead of a full sort
             auto later = [&](int a, int b) { return t[a] > t[b] || (t[a] == t[b] && a > b); };
             std::make_heap(order.begin(), order.end(), later);
-            for (int i = 0; i < n; ++i) {   // p = W'd
-                const double di = d[i];
-                if (di == 0.0) continue;
-                const double* yr = &mem.Yt[(size_t)i * m];
-                const double* sr = &mem.St[(size_t)i * m];
-                for (int j = 0; j < col; ++j) {
-                    p[j] += yr[j] * di;
-                    p[col + j] += sr[j] * di;
-                }
-            }
-            for (int j = 0; j < col; ++j) p[col + j] *= theta;
+            mem.Wt_times(d.data(), p.data());   // p = W'd  (d is zero on the variables that do not move)
             double fp = -dtd;
             double fpp = -theta * fp;
             if (col > 0) {
@@ -460,13 +463,13 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 fp += dt * fpp + gb * gb + theta * gb * zb;
                 fpp -= theta * gb * gb;
                 if (col > 0) {
+                    // M is symmetric (the inverse of the symmetric middle matrix): one product M·w_b serves
+                    // w_b'Mc, w_b'Mp and w_b'Mw_b -- this loop runs once per variable that reaches its bound
+                    // (hundreds per iteration on arbitrage problems, where most prices end on their bound)
                     mem.w_row(b, wb.data());
-                    mem.M_times(c, v1);       // M c
-                    mem.M_times(p, v2);       // M p
-                    double wMc = 0, wMp = 0, wMw = 0;
-                    for (int j = 0; j < k2; ++j) { wMc += wb[j] * v1[j]; wMp += wb[j] * v2[j]; }
                     mem.M_times(wb, v1);
-                    for (int j = 0; j < k2; ++j) wMw += wb[j] * v1[j];
+                    double wMc = 0, wMp = 0, wMw = 0;
+                    for (int j = 0; j < k2; ++j) { wMc += v1[j] * c[j]; wMp += v1[j] * p[j]; wMw += v1[j] * wb[j]; }
                     fp -= gb * wMc;
                     fpp -= 2.0 * gb * wMp + gb * gb * wMw;
                     for (int j = 0; j < k2; ++j) p[j] += gb * wb[j];
@@ -492,46 +495,54 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             if (!fixed[i]) free_idx.push_back(i);
         if (col > 0 && !free_idx.empty()) {
             const int nf = (int)free_idx.size();
-            // r = Z'(g + θ(xcp − x) − W M c)
-            r.resize(nf);
+            // r = Z'(g + θ(xcp − x) − W M c), kept as a full-length vector that is zero on the fixed variables
+            rfull.assign(n, 0.0);
             mem.M_times(c, Mc);
-            for (int j = 0; j < col; ++j) Mc[col + j] *= theta;   // fold θ of W = [Y θS] into the coefficients
+            mem.W_times_add(Mc.data(), rfull.data());                 // W M c
+            for (int i = 0; i < n; ++i)
+                rfull[i] = fixed[i] ? 0.0 : g[i] + theta * (xcp[i] - x[i]) - rfull[i];
             wzr.assign(k2, 0.0);
-            for (int a = 0; a < nf; ++a) {
-                const int i = free_idx[a];
-                const double* yr = &mem.Yt[(size_t)i * m];
-                const double* sr = &mem.St[(size_t)i * m];
-                double wmc = 0.0;
-                for (int j = 0; j < col; ++j) wmc += yr[j] * Mc[j] + sr[j] * Mc[col + j];
-                const double ra = g[i] + theta * (xcp[i] - x[i]) - wmc;
-                r[a] = ra;
-                for (int j = 0; j < col; ++j) {      // W'Z r
-                    wzr[j] += yr[j] * ra;
-                    wzr[col + j] += sr[j] * ra;
-                }
-            }
-            for (int j = 0; j < col; ++j) wzr[col + j] *= theta;
+            mem.Wt_times(rfull.data(), wzr.data());                   // W'Z r
             // W'Z Z'W: a sum of k2×k2 outer products over the FREE variables -- or, when fewer variables are
             // fixed than free (the usual case away from a corner of the box), W'W from the stored inner
             // products minus the outer products of the FIXED rows: O(min(free, fixed)·(2m)²) instead of O(n·(2m)²)
+            // W'ZZ'W.  Few fixed (or few free) variables: W'W from the stored inner products minus (or just) the
+            // outer products of those rows, O(min(free, fixed)·(2m)²) with strided row gathers.  Otherwise: the
+            // masked Gram matrix as (2m)(2m+1)/2 contiguous dot products of length n (vectorised), O(n·(2m)²/2).
             const int nfix = n - nf;
-            if (nfix < nf) {
-                mem.WtW(WZ);
-                for (int i = 0; i < n; ++i) {
-                    if (!fixed[i]) continue;
-                    mem.w_row(i, wb.data());
-                    for (int j = 0; j < k2; ++j) {
-                        const double wj = wb[j];
-                        for (int q = 0; q < k2; ++q) WZ[j * k2 + q] -= wj * wb[q];
+            if (std::min(nf, nfix) <= 24) {
+                if (nfix < nf) {
+                    mem.WtW(WZ);
+                    for (int i = 0; i < n; ++i) {
+                        if (!fixed[i]) continue;
+                        mem.w_row(i, wb.data());
+                        for (int j = 0; j < k2; ++j) {
+                            const double wj = wb[j];
+                            for (int q = 0; q < k2; ++q) WZ[j * k2 + q] -= wj * wb[q];
+                        }
+                    }
+                } else {
+                    WZ.assign((size_t)k2 * k2, 0.0);
+                    for (int a = 0; a < nf; ++a) {
+                        mem.w_row(free_idx[a], wb.data());
+                        for (int j = 0; j < k2; ++j) {
+                            const double wj = wb[j];
+                            for (int q = 0; q < k2; ++q) WZ[j * k2 + q] += wj * wb[q];
+                        }
                     }
                 }
             } else {
                 WZ.assign((size_t)k2 * k2, 0.0);
-                for (int a = 0; a < nf; ++a) {
-                    mem.w_row(free_idx[a], wb.data());
-                    for (int j = 0; j < k2; ++j) {
-                        const double wj = wb[j];
-                        for (int q = 0; q < k2; ++q) WZ[j * k2 + q] += wj * wb[q];
+                masked.resize(n);
+                for (int a = 0; a < k2; ++a) {
+                    const double* wa = a < col ? mem.Ycol(a) : mem.Scol(a - col);
+                    const double sa = a < col ? 1.0 : theta;
+                    for (int i = 0; i < n; ++i) masked[i] = fixed[i] ? 0.0 : sa * wa[i];
+                    for (int b = a; b < k2; ++b) {
+                        const double* wbcol = b < col ? mem.Ycol(b) : mem.Scol(b - col);
+                        const double g_ab = (b < col ? 1.0 : theta) * dotn(masked.data(), wbcol, n);
+                        WZ[a * k2 + b] = g_ab;
+                        WZ[b * k2 + a] = g_ab;
                     }
                 }
             }
@@ -548,14 +559,11 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             if (solve_dense(N, v, k2, 1)) {
                 // d̂ = −(1/θ) r − (1/θ²) Z'W v
                 du.resize(nf);
-                for (int j = 0; j < col; ++j) v[col + j] *= theta;
+                wvfull.assign(n, 0.0);
+                mem.W_times_add(v.data(), wvfull.data());             // W v
                 for (int a = 0; a < nf; ++a) {
                     const int i = free_idx[a];
-                    const double* yr = &mem.Yt[(size_t)i * m];
-                    const double* sr = &mem.St[(size_t)i * m];
-                    double wv = 0.0;
-                    for (int j = 0; j < col; ++j) wv += yr[j] * v[j] + sr[j] * v[col + j];
-                    du[a] = -r[a] / theta - wv / (theta * theta);
+                    du[a] = -rfull[i] / theta - wvfull[i] / (theta * theta);
                 }
                 // MN11: project the subspace minimizer onto the box; keep it if it is a descent
                 // direction for the objective, otherwise truncate the step (v2.1 behaviour).
