@@ -267,10 +267,10 @@ def main():
     # unavailable or disagrees anywhere, ALL ranks use the RCCL all-reduce instead.
     peer, fused_peer, peer_ptrs, n_fused = None, False, None, 0
     if use_dist and not args.rccl and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
-        from cfmmrouter_amd.dist import PeerAllReduce
-        peer = PeerAllReduce.create(n + 1, None, torch.device("cuda", local_rank))  # None -> RCCL fallback
+        from cfmmrouter_amd.dist import open_peer_buffers
+        peer = open_peer_buffers(be.ctx, None, torch.device("cuda", local_rank))  # None (on every rank) -> RCCL fallback
         if peer is not None:
-            peer_ptrs = [int(p) for p in peer.hdl.buffer_ptrs]
+            peer_ptrs = list(peer.ptrs)
             good = True
             for _ in range(3):
                 be.ctx.set_peers(peer_ptrs, world, rank, n_fused)
@@ -541,6 +541,7 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
                    "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
                    "sharding": ((f"pools x{world}, fold + one-shot xGMI peer all-reduce of n_tokens+1 f64 in one launch per step"
+                                 + (" (buffers: library IPC export)" if type(peer).__name__ == "IpcPeers" else " (buffers: torch symmetric memory)")
                                  if fused_peer else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
                                 if use_dist else "single GPU, no collective")},
         "roofline": roofline,
@@ -563,6 +564,8 @@ def main():
     if ring_ctx:
         for b_ in ring_ctx[1:]:
             b_.close()
+    if peer is not None and hasattr(peer, "close"):
+        peer.close()
     be.close()
     if rank == 0:
         print(json.dumps(line))

@@ -123,6 +123,10 @@ def lib():
     L.cfmm_set_peers.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64]
     L.cfmm_peer_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_uint64, C.c_void_p]
+    L.cfmm_peer_buffer_alloc.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_char_p]
+    L.cfmm_peer_buffer_open.argtypes = [_ctx, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.cfmm_peer_buffer_close.argtypes = [_ctx, C.c_uint64]
+    L.cfmm_peer_buffer_free.argtypes = [_ctx, C.c_uint64]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
     L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p, _i32p]
@@ -320,6 +324,24 @@ class Context:
         all-reduce over the given symmetric buffers (cfmm_set_peers).  world=0 switches it off."""
         arr = (C.c_uint64 * max(world, 1))(*[int(p) for p in peer_ptrs][:max(world, 1)]) if world else None
         self._check(self._L.cfmm_set_peers(self._h, arr, int(world), int(rank), C.c_uint64(int(seq))))
+
+    def peer_buffer_alloc(self):
+        """This rank's symmetric buffer for cfmm_set_peers -> (device pointer, 64-byte IPC handle)."""
+        p = C.c_uint64()
+        h = C.create_string_buffer(64)
+        self._check(self._L.cfmm_peer_buffer_alloc(self._h, C.byref(p), h))
+        return p.value, h.raw
+
+    def peer_buffer_open(self, handle: bytes) -> int:
+        p = C.c_uint64()
+        self._check(self._L.cfmm_peer_buffer_open(self._h, C.create_string_buffer(bytes(handle), 64), C.byref(p)))
+        return p.value
+
+    def peer_buffer_close(self, ptr_: int):
+        self._check(self._L.cfmm_peer_buffer_close(self._h, C.c_uint64(int(ptr_))))
+
+    def peer_buffer_free(self, ptr_: int):
+        self._check(self._L.cfmm_peer_buffer_free(self._h, C.c_uint64(int(ptr_))))
 
     def sweep_dev(self, d_v_ptr: int, d_out_ptr: int, materialize: bool):
         self._check(self._L.cfmm_sweep_dev(self._h, C.c_void_p(d_v_ptr), C.c_void_p(d_out_ptr),

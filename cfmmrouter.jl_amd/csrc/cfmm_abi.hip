@@ -31,6 +31,11 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
+// Kernel arguments in device memory: measured 22.2 vs 24.9 us per config-3 step and 7.0 vs 9.1 us per config-2
+// step against host-memory kernargs (r01).  The HIP runtime reads the variable when it initialises, so it is
+// set when this library is loaded -- unless the caller has decided otherwise (an existing value is kept).
+__attribute__((constructor)) void cfmm_default_environment() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 struct Segment {
     int kind = 0;
     int64_t m = 0;
@@ -1582,6 +1587,59 @@ int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int
         const double t = atof(e);
         if (t > 0.0) c->peer_timeout_ticks = (long long)(t * 1e8);
     }
+    return CFMM_OK;
+}
+
+int cfmm_peer_buffer_alloc(cfmm_ctx* c, uint64_t* d_buf, unsigned char handle[CFMM_IPC_HANDLE_BYTES])
+{
+    if (!c || !d_buf || !handle) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_peer_buffer_alloc");
+    static_assert(sizeof(hipIpcMemHandle_t) == CFMM_IPC_HANDLE_BYTES, "IPC handle size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)(6 * (c->n + 1) + 2) * sizeof(double);
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(c, CFMM_ERR_HIP, "peer buffer export failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+    }
+    std::memcpy(handle, &h, sizeof h);
+    *d_buf = reinterpret_cast<uint64_t>(p);
+    return CFMM_OK;
+}
+
+int cfmm_peer_buffer_open(cfmm_ctx* c, const unsigned char handle[CFMM_IPC_HANDLE_BYTES], uint64_t* d_peer)
+{
+    if (!c || !d_peer || !handle) return CFMM_ERR_INVALID_ARG;
+    CFMM_SINGLE_ONLY(c, "cfmm_peer_buffer_open");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof h);
+    void* p = nullptr;
+    HIP_TRY(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *d_peer = reinterpret_cast<uint64_t>(p);
+    return CFMM_OK;
+}
+
+int cfmm_peer_buffer_close(cfmm_ctx* c, uint64_t d_peer)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipIpcCloseMemHandle(reinterpret_cast<void*>(d_peer)));
+    return CFMM_OK;
+}
+
+int cfmm_peer_buffer_free(cfmm_ctx* c, uint64_t d_buf)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(reinterpret_cast<void*>(d_buf)));
     return CFMM_OK;
 }
 

@@ -95,6 +95,68 @@ class PeerAllReduce:
         return par if float(flag.item()) == 1.0 else None
 
 
+class IpcPeers:
+    """The symmetric buffers of cfmm_set_peers through the LIBRARY's own IPC export
+    (cfmm_peer_buffer_alloc / _open: hipIpcGetMemHandle / hipIpcOpenMemHandle) -- no private torch
+    API; torch.distributed only carries the 64-byte handles (any launcher's channel would do).
+    `ptrs[p]` is rank p's buffer mapped into this process (own rank: the allocation itself)."""
+
+    def __init__(self, ctx, group):
+        import torch.distributed as dist
+
+        self.ctx, self.group = ctx, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.own, handle = ctx.peer_buffer_alloc()
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle, group=group)
+        self.ptrs = [self.own if p == self.rank else ctx.peer_buffer_open(handles[p]) for p in range(self.world)]
+        dist.barrier(group=group)       # every rank has mapped every buffer before anybody writes
+
+    def close(self):
+        import torch.distributed as dist
+        try:
+            self.ctx.set_peers([], 0, 0, 0)
+            for p, ptr_ in enumerate(self.ptrs):
+                if p != self.rank:
+                    self.ctx.peer_buffer_close(ptr_)
+            dist.barrier(group=self.group)   # nobody still maps the buffer that is about to be freed
+            self.ctx.peer_buffer_free(self.own)
+        except Exception:
+            pass
+        self.ptrs = []
+
+
+def open_peer_buffers(ctx, group, device):
+    """Symmetric buffers for `ctx` on every rank of `group`, or None on ALL ranks (collective vote):
+    first the library's own IPC export, then torch's symmetric memory (nccl groups only).
+    Returns an object with `.ptrs` (and `.close()` for the IPC flavour)."""
+    import torch
+    import torch.distributed as dist
+
+    def vote(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64,
+                         device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return float(t.item()) == 1.0
+
+    peers = None
+    try:
+        peers = IpcPeers(ctx, group)
+    except Exception:
+        peers = None
+    if vote(peers is not None):
+        return peers
+    if peers is not None:
+        peers.close()
+    if dist.get_backend(group) != "nccl":
+        return None
+    sym = PeerAllReduce.create(ctx.n_tokens + 1, group, device)   # votes internally
+    if sym is None:
+        return None
+    sym.ptrs = [int(p) for p in sym.hdl.buffer_ptrs]
+    return sym
+
+
 def shard_range(m: int, rank: int, world: int):
     """Contiguous block [lo, hi) of m items owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(int(m), int(world))
@@ -198,14 +260,15 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
         dev = rank if device is None else device
         backend = DeviceBackend(n_tokens, local, device=dev)
         import os
-        if dist.get_backend(group) == "nccl" and n_tokens <= 8192 and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
-            # fast path: the all-reduce happens INSIDE the library at the end of every sweep
-            # (cfmm_set_peers), so find_arb_/route_ -- including the one-call native route! -- work on
-            # the global market unchanged.  Falls through to ShardedBackend (RCCL) if unavailable.
+        if torch.cuda.is_available() and n_tokens <= 8192 and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
+            # fast path: the all-reduce happens INSIDE the library, in the launch that folds the partial rows
+            # (cfmm_set_peers), so find_arb_/route_ -- including the one-call native route! -- work on the
+            # global market unchanged.  Falls through to ShardedBackend (torch.distributed all-reduce) when no
+            # rank-to-rank mapping can be set up.
             with torch.cuda.device(dev):
-                peer = PeerAllReduce.create(n_tokens + 1, group, torch.device("cuda", dev))
-            if peer is not None:
-                backend.ctx.set_peers([int(p) for p in peer.hdl.buffer_ptrs], world, rank, 0)   # the granules are fresh
-                backend.peer = peer   # keeps the symmetric allocation alive
+                peers = open_peer_buffers(backend.ctx, group, torch.device("cuda", dev))
+            if peers is not None:
+                backend.ctx.set_peers(peers.ptrs, world, rank, 0)   # the granules are fresh
+                backend.peer = peers   # keeps the mappings alive
                 return Router(objective, local, n_tokens, _backend=backend)
     return Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))

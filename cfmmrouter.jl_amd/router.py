@@ -59,6 +59,10 @@ class DeviceBackend:
                 _upload(self.ctx, b)
 
     def close(self):
+        peer = getattr(self, "peer", None)
+        if peer is not None and hasattr(peer, "close"):
+            peer.close()       # unmap / free the IPC peer buffers while the context still exists
+            self.peer = None
         self.ctx.close()
 
 

@@ -213,6 +213,18 @@ int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t 
  * is NaN and host-pointer calls fail with CFMM_ERR_STATE.  world = 0 switches sharding off. */
 int cfmm_set_peers(cfmm_ctx* ctx, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq);
 
+/* The symmetric buffers of cfmm_set_peers without any framework: every rank allocates its buffer
+ * (sized and zeroed for the context's n_tokens), publishes the 64-byte IPC handle through whatever channel
+ * its launcher has (MPI, torch.distributed, a file), and maps the other ranks' buffers from their handles
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver stack).
+ * The pointers go to cfmm_set_peers (own rank: the pointer from _alloc).  _close unmaps a peer's buffer,
+ * _free releases the own one (after every peer has closed it). */
+#define CFMM_IPC_HANDLE_BYTES 64
+int cfmm_peer_buffer_alloc(cfmm_ctx* ctx, uint64_t* d_buf, unsigned char handle[CFMM_IPC_HANDLE_BYTES]);
+int cfmm_peer_buffer_open(cfmm_ctx* ctx, const unsigned char handle[CFMM_IPC_HANDLE_BYTES], uint64_t* d_peer);
+int cfmm_peer_buffer_close(cfmm_ctx* ctx, uint64_t d_peer);
+int cfmm_peer_buffer_free(cfmm_ctx* ctx, uint64_t d_buf);
+
 /* ---- route! without an interpreter in the loop ----------------------- */
 
 #define CFMM_OBJ_LINEAR_NONNEGATIVE 0 /* LinearNonnegative(c)      src/objectives.jl:51-79 */

@@ -1,8 +1,9 @@
-mkdir -p gpurun_out; rm -f gpurun_out/exp_pf2.txt
-for rep in 1 2; do
-for lib in libcfmm_amd.so libcfmm_pf.so; do
-for w in config3 product1m config5; do
-CFMM_AMD_LIB=$PWD/cfmmrouter.jl_amd/$lib timeout 300 python scripts/exp.py $w "" 2>&1 | grep -v "amdgpu.ids\|^#" | sed "s/^/$lib $w /" | tee -a gpurun_out/exp_pf2.txt
+mkdir -p gpurun_out
+for w in config3 config4shard config5 config2; do
+  timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu --no-cold --workload $w > gpurun_out/bench_${w}.log 2>&1 < /dev/null
+  tail -1 gpurun_out/bench_${w}.log | python -c "
+import sys,json
+l=json.loads(sys.stdin.readline()); print('$w', 'step us %.2f'%(1e3*l['ms_per_step']), 'route', l.get('route'))
+"
 done
-done
-done
+timeout 600 python -m pytest tests -m gpu -x -q -k "route or lbfgs or golden" 2>&1 | tail -3

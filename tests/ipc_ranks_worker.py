@@ -1,0 +1,57 @@
+"""Two (or more) PROCESSES sharing one MI355X, launched by tests/test_gpu_dist.py through
+torch.distributed.run with the gloo backend (RCCL refuses two ranks on one device): the sharded route!
+with the library's own IPC peer buffers (cfmm_peer_buffer_alloc/_open) and the fold + gather launch --
+a real multi-process run of the N > 1 path, minus the xGMI links.  Prints one JSON line on rank 0."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import dist as crd
+from cfmmrouter_amd import synth
+
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 512
+market = [synth.product_pools(300_000, n, seed=81), synth.geomean_pools(100_000, n, seed=82),
+          synth.bounded_product_pools(60_000, n, seed=83, consistent=True)]
+obj = cr.LinearNonnegative(synth.linear_prices(n, seed=81))
+r = crd.ShardedRouter(obj, market, n, device=0)
+out = {"world": world, "in_library_collective": isinstance(r._backend, cr.DeviceBackend),
+       "buffers": type(getattr(r._backend, "peer", None)).__name__}
+v = synth.sweep_prices(n, seed=84)
+cr.find_arb_(r, v)
+psi_fixed = cr.netflows(r).copy()
+cr.route_(r, v=np.ones(n), solver="native")
+psi_native, v_native, ev_native = cr.netflows(r).copy(), r.v.copy(), r.info["funcalls"]
+cr.route_(r, v=np.ones(n), solver="scipy")
+psi_scipy = cr.netflows(r).copy()
+gathered = [None] * world
+dist.all_gather_object(gathered, (psi_fixed, psi_native, v_native, len(r.Δs)))
+if rank == 0:
+    single = cr.Router(obj, market, n, device=0)
+    cr.find_arb_(single, v)
+    ref_fixed = cr.netflows(single).copy()
+    cr.route_(single, v=np.ones(n), solver="native")
+    ref_native = cr.netflows(single).copy()
+    scale = np.max(np.abs(ref_native))
+    out.update(
+        ranks_bit_identical=all(np.array_equal(g[0], gathered[0][0]) and np.array_equal(g[1], gathered[0][1]) and
+                                np.array_equal(g[2], gathered[0][2]) for g in gathered),
+        pools_total=sum(g[3] for g in gathered),
+        fixed_v_rel_diff=float(np.max(np.abs(psi_fixed - ref_fixed)) / np.max(np.abs(ref_fixed))),
+        route_native_rel_diff=float(np.max(np.abs(psi_native - ref_native)) / scale),
+        route_scipy_rel_diff=float(np.max(np.abs(psi_scipy - ref_native)) / scale),
+        evaluations=ev_native)
+    single.close()
+    print("IPC_RANKS " + json.dumps(out), flush=True)
+r.close()
+dist.barrier()
+dist.destroy_process_group()

@@ -79,3 +79,22 @@ def test_bench_single_process_multi_device_and_cold_only():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["roofline"]["residency"].startswith("hbm-resident") and line["roofline"]["warm"] is None
     assert 0.2 < line["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_route_across_processes_sharing_one_gpu(world):
+    """A real multi-process run of the N > 1 path on the 1-GPU box: `world` processes (gloo rendezvous; RCCL
+    does not allow two ranks on one device) each own a shard, exchange the library's IPC buffer handles,
+    and every sweep's fold launch gathers the other processes' {Ψ, acc} from their mapped buffers."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ipc_ranks_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CFMM_AMD_PEER_TIMEOUT_S="20")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("IPC_RANKS ")][-1][len("IPC_RANKS "):])
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"ipc_ranks_world{world}.json"), "w"), indent=1)
+    assert out["world"] == world and out["in_library_collective"] and out["buffers"] == "IpcPeers"
+    assert out["ranks_bit_identical"] and out["pools_total"] == 460_000
+    assert out["fixed_v_rel_diff"] <= 1e-13
+    assert out["route_native_rel_diff"] <= 1e-6 and out["route_scipy_rel_diff"] <= 1e-6 and out["evaluations"] >= 5
