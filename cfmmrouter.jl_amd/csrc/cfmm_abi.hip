@@ -510,7 +510,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool inline_fold = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
                              c->n <= kMaxFoldTokens && c->d_sync != nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
-    const bool flagged = want_host_flag && !gb && !sharded && c->rows_total > 0 && c->d_sync != nullptr;
+    const bool flagged = want_host_flag && !gb && (sharded || c->rows_total > 0) && c->d_sync != nullptr;
     c->last_inline = inline_fold;
     c->last_flagged = flagged;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -608,6 +608,9 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         ps.count = count;
         ps.seq = ++c->peer_seq;
         ps.timeout_ticks = c->peer_timeout_ticks;
+        ps.sync = c->d_sync;
+        ps.host_flag = flagged ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
+        ps.host_seq = flagged ? ++c->flag_seq : 0;
         hipError_t e = launch_reduce_gather(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream,
                                             c->groups.empty() ? kSmallBlock : c->groups.back().block, ps, ra, rb);
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "fold + gather launch failed: %s", hipGetErrorString(e));
@@ -673,7 +676,7 @@ int host_sweep_end(cfmm_ctx* c)
 {
     double* h_out = c->h_stage + c->n;
     bool flag_seen = false;
-    if (c->peers.empty() && c->last_flagged) {
+    if (c->last_flagged) {
         // The last fold block wrote {Ψ, acc} through to this pinned buffer and then raised the flag
         // (PCIe posted writes stay ordered): poll it instead of waiting for the kernel's end-of-pipe
         // processing and its completion signal.  Bounded; falls back to a stream wait.

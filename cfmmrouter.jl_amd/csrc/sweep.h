@@ -148,6 +148,9 @@ struct PeerSet {
     long long count;                        // n_tokens + 1
     unsigned long long seq;                 // 1, 2, ... identical on every rank
     long long timeout_ticks;                // wall_clock64() ticks (100 MHz) before a wait gives up (NaN output)
+    unsigned* sync;                         // the context's ticket words (fold_finish), for the host flag
+    unsigned long long* host_flag;          // optional: raised (= host_seq) once all of `out` (mapped host memory) is written
+    unsigned long long host_seq;
 };
 hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                                 const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

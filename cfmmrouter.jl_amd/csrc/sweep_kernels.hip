@@ -936,7 +936,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict_
     ok = __all(ok);
     double s = 0.0;                                       // rank order on every rank: bit-identical results
     for (int p = 0; p < ps.world; ++p) s += __shfl(p < 8 ? x[0] : x[1], (p & 7) * kReduceCols + c, 64);
-    if (tid < kReduceCols && col < n1) out[col] = ok ? s : __builtin_nan("");
+    fold_finish(s, ok, n1, out, ps.sync, (int)gridDim.x, false, ps.host_flag, ps.host_seq);
 }
 
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat

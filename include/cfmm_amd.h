@@ -91,8 +91,13 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * exchange v / Psi through mapped pinned memory instead of copy commands), "fuse_segments" (default 1: all
  * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate
  * GeometricMeanTwoCoin with pow in the reference's operation order instead of the default
- * log-space form; both are within 1e-12 of the reference).  Unknown keys are
- * CFMM_ERR_INVALID_ARG. */
+ * log-space form; both are within 1e-12 of the reference), "xcd_map" (fused launches: 1 = default, XCD-aware
+ * block -> segment map weighted by pools x cost per pool; 2 = XCD-aware with equal cost per pool; 0 = block b ->
+ * segment b % nseg), "cost_geomean" / "cost_univ3" (cost of one evaluation in tenths of a ProductTwoCoin one, used
+ * by that map; defaults 18 / 14), "wave_split" (default 0; 1 = every block of a fused launch sweeps every segment,
+ * its wavefronts dealt to the families).  Unknown keys are CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
+ * is set to 1 when the library is loaded unless already set (kernel arguments in device memory: -10 % per step);
+ * CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */
 int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);
 int cfmm_get_option(const cfmm_ctx* ctx, const char* key, int64_t* value);
 
