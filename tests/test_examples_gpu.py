@@ -51,3 +51,11 @@ def test_univ3_example(capsys):
     D, L = orc.UniV3(15.0, [30.0, 20, 10, 5], [1.0, 2.0, 1.5, 0.0], 0.997).find_arb([25.0, 1.0])
     np.testing.assert_array_equal(Δ, D)
     np.testing.assert_array_equal(Λ, L)
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0,0"])
+def test_sequential_sharded_example(devices, capsys):
+    import sequential_sharded
+    first, second = sequential_sharded.main(devices)
+    assert "round 2" in capsys.readouterr().out
+    assert first > 1e3 and abs(second) <= 1e-6 * first      # the market is cleared after one pass
