@@ -703,6 +703,9 @@ int host_sweep_end(cfmm_ctx* c)
     for (int j = 0; j <= c->n; ++j)
         if (!std::isfinite(c->last_out[(size_t)j])) {
             c->have_out = false;
+            // a fold that gave up may have left its arrival / ticket words non-zero: clean them for the next sweep
+            (void)hipStreamSynchronize(c->stream);
+            if (c->d_sync) (void)hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned));
             if (!c->peers.empty())
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
                                                "publish) or a shard overflowed", j);

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_examples_gpu.py -m gpu -x -q > gpurun_out/pytest_x.log 2>&1 < /dev/null; tail -25 gpurun_out/pytest_x.log
+for i in 1 2; do timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$i.log 2>&1 < /dev/null; tail -3 gpurun_out/pytest_gpu_$i.log; done
