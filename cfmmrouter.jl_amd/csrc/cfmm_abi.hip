@@ -163,6 +163,9 @@ struct cfmm_ctx {
                                    // 2 = XCD-aware with equal cost per pool, 0 = block b -> segment b % nseg
     int64_t opt_cost_geomean = 18; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one
     int64_t opt_cost_univ3 = 14;
+    int64_t opt_alternate = 1;     // 1: consecutive sweeps walk the tiles in alternating directions (L2 reuse across sweeps);
+                                   //    results of two sweeps at the same v then agree to rounding, not bit for bit
+    uint64_t sweep_count = 0;
     int64_t opt_inline_fold = 0;   // 1: partial rows are folded inside the sweep launch (single-launch evaluations, n <= kMaxFoldTokens);
                                    //    measured 1-3 us per step SLOWER than the separate fold launch, kept as an option
     int64_t opt_host_flag = 1;     // 1: zero-copy host-pointer sweeps end by raising a flag in mapped host memory that the
@@ -529,6 +532,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
         a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
+        a.reverse = c->opt_alternate != 0 ? (int)(c->sweep_count & 1) : 0;
         a.fold_blocks = inline_fold ? (c->n + 1 + kReduceCols - 1) / kReduceCols : 0;
         a.sync = c->d_sync;
         a.fold_out = d_out;
@@ -633,6 +637,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         c->pending.push_back({ra, rb, 1});
     }
     if (materialize) c->have_trades = true;
+    ++c->sweep_count;
     return CFMM_OK;
 }
 
@@ -1174,6 +1179,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "univ3_coop")) return &c->opt_univ3_coop;
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
+    if (!std::strcmp(key, "alternate")) return &c->opt_alternate;
     if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
     if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;
     if (!std::strcmp(key, "cost_univ3")) return &c->opt_cost_univ3;

@@ -58,6 +58,8 @@ struct SweepArgs {
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int nt_stores;               // trade stores: 0 plain, 1 non-temporal, 2 write-through
+    int reverse;                 // 1: every lane walks its tiles last-to-first (alternates between consecutive sweeps, so a
+                                 //    sweep starts on the pool data the previous one left in the XCD's L2)
     // In-launch row fold (fold_blocks > 0): the first fold_blocks blocks of the grid do not sweep;
     // they wait until every sweeping block has published its partial row (write-through stores +
     // arrival counters, no release fence) and then fold the rows into fold_out -- the work of

@@ -551,26 +551,34 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         // before the arithmetic -- and the overlap verified in the ISA: +-0 on every workload, with or
         // without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt).  Not kept: it
         // only costs registers.)
+        // Tile order alternates between consecutive sweeps (a.reverse): block-strided "phases" are walked
+        // first-to-last by one sweep and last-to-first by the next, so each sweep begins on the pool data the
+        // previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
+        // 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
+        // same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
         const int64_t stride = (int64_t)nblocks * sub_block;
-        int64_t i = (int64_t)bid * sub_block + sub_tid;
+        const int64_t i0 = (int64_t)bid * sub_block + sub_tid;
+        int64_t left = i0 < a.m ? (a.m - i0 + stride - 1) / stride : 0;      // tiles of this lane
+        const int64_t step = a.reverse ? -stride : stride;
+        int64_t i = a.reverse ? i0 + (left - 1) * stride : i0;
         typename Ops::Raw cur = {};
-        bool ok = i < a.m;
+        bool ok = left > 0;
         if (ok) cur = ops.load(i);
         if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
         if constexpr (Ops::kWaveCooperative) {
             while (__any(ok)) {                          // the wavefront stays together
                 process(cur, i, ok);
                 if (ok) {
-                    i += stride;
-                    ok = i < a.m;
+                    i += step;
+                    ok = --left > 0;
                     if (ok) cur = ops.load(i);
                 }
             }
         } else {
             while (ok) {
                 process(cur, i, true);
-                i += stride;
-                ok = i < a.m;
+                i += step;
+                ok = --left > 0;
                 if (ok) cur = ops.load(i);
             }
         }
@@ -578,7 +586,9 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
         const int64_t tile_pools = (int64_t)sub_block * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-        for (int64_t tile = bid; tile < n_tiles; tile += nblocks) {   // uniform trip count within the group
+        const int64_t mine = bid < n_tiles ? (n_tiles - bid + nblocks - 1) / nblocks : 0;
+        for (int64_t k = 0; k < mine; ++k) {   // uniform trip count within the group
+            const int64_t tile = bid + (a.reverse ? mine - 1 - k : k) * nblocks;
             const int64_t base = tile * tile_pools + sub_tid;
             typename Ops::Raw raw[U] = {};
             bool ok[U];

@@ -1,9 +1,4 @@
-mkdir -p gpurun_out
-for w in config3 config4shard config5 config2; do
-  timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu --no-cold --workload $w > gpurun_out/bench_${w}.log 2>&1 < /dev/null
-  tail -1 gpurun_out/bench_${w}.log | python -c "
-import sys,json
-l=json.loads(sys.stdin.readline()); print('$w', 'step us %.2f'%(1e3*l['ms_per_step']), 'route', l.get('route'))
-"
+mkdir -p gpurun_out; rm -f gpurun_out/exp_alt.txt
+for w in config3 product1m config4shard config5 config2; do
+timeout 300 python scripts/exp.py $w "alternate=0" "alternate=1" 2>&1 | grep -v "amdgpu.ids\|^#" | sed "s/^/$w /" | tee -a gpurun_out/exp_alt.txt
 done
-timeout 600 python -m pytest tests -m gpu -x -q -k "route or lbfgs or golden" 2>&1 | tail -3

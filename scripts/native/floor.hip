@@ -38,6 +38,35 @@ __global__ __launch_bounds__(256) void copy_k(const double2* __restrict__ a, dou
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) b[i] = a[i];
 }
 
+// read-only stream: every lane sums 16-byte loads; one partial per block (what a FUSED sweep's memory side is)
+__global__ __launch_bounds__(256) void read_k(const double2* __restrict__ a, double* __restrict__ out, long n)
+{
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double2 x = a[i];
+        s += x.x + x.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.x], s);
+}
+
+// the same read-only stream with a per-launch direction: block-strided "phases" k = 0..K-1 walked forwards or
+// backwards, as a sweep's tile loop would -- does the XCD's 4 MB L2 keep the tail of the previous launch?
+__global__ __launch_bounds__(256) void read_dir_k(const double2* __restrict__ a, double* __restrict__ out, long n, int reverse)
+{
+    const long stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + threadIdx.x;
+    const long count = first < n ? (n - first + stride - 1) / stride : 0;
+    double s = 0.0;
+    for (long k = 0; k < count; ++k) {
+        const long i = first + (reverse ? count - 1 - k : k) * stride;
+        const double2 x = a[i];
+        s += x.x + x.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.x], s);
+}
+
 template <class F>
 static double span_us(F launch, hipStream_t s, int reps = 200)
 {
@@ -81,6 +110,38 @@ int main()
         }
         hipFree(a);
         hipFree(b);
+    }
+    for (double mb : {32.0, 44.0, 88.0}) {   // read-only streams, cache-warm
+        const long n = (long)(mb * 1e6 / 16);
+        double2* a;
+        double* o;
+        hipMalloc(&a, n * 16);
+        hipMalloc(&o, 4096 * 8);
+        hipMemset(a, 0, n * 16);
+        hipMemset(o, 0, 4096 * 8);
+        for (int grid : {512, 1024, 2048}) {
+            const double us = span_us([&](hipEvent_t x, hipEvent_t y) { hipExtLaunchKernelGGL(read_k, dim3(grid), dim3(256), 0, s, x, y, 0, a, o, n); }, s, 100);
+            printf("read %5.1f MB grid %4d: %6.2f us = %5.2f TB/s\n", mb, grid, us, mb * 1e6 / us / 1e6);
+        }
+        hipFree(a);
+        hipFree(o);
+    }
+    for (double mb : {44.0, 64.0}) {   // alternating direction between launches vs always forwards
+        const long n = (long)(mb * 1e6 / 16);
+        double2* a;
+        double* o;
+        hipMalloc(&a, n * 16);
+        hipMalloc(&o, 4096 * 8);
+        hipMemset(a, 0, n * 16);
+        hipMemset(o, 0, 4096 * 8);
+        for (int alt = 0; alt < 2; ++alt) {
+            int launch = 0;
+            const double us = span_us([&](hipEvent_t x, hipEvent_t y) {
+                hipExtLaunchKernelGGL(read_dir_k, dim3(512), dim3(256), 0, s, x, y, 0, a, o, n, alt ? (launch++ & 1) : 0); }, s, 100);
+            printf("read %5.1f MB, tile order %s: %6.2f us = %5.2f TB/s\n", mb, alt ? "alternating" : "always forwards", us, mb * 1e6 / us / 1e6);
+        }
+        hipFree(a);
+        hipFree(o);
     }
     // HBM-resident copy: rotate over 6 buffer pairs of 72 MB (432 MB > the 256 MB Infinity Cache)
     {

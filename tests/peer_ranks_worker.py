@@ -24,6 +24,8 @@ count = n + 1
 bufs = [torch.zeros(6 * count + 2, dtype=torch.float64, device="cuda") for _ in range(world)]
 ptrs = [b.data_ptr() for b in bufs]
 ranks = [cr.DeviceBackend(n, shard_batches(market, r, world)) for r in range(world)]
+for be in ranks:
+    be.ctx.set_option("alternate", 0)   # local and sharded sweeps are compared bit for bit: same tile direction every time
 outs = [torch.zeros(count, dtype=torch.float64, device="cuda") for _ in range(world)]
 loc = [torch.zeros(count, dtype=torch.float64, device="cuda") for _ in range(world)]
 torch.cuda.synchronize()

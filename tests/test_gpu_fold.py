@@ -193,10 +193,13 @@ def test_fused_launch_block_maps_agree_with_oracle(opts, families):
     try:
         psi, acc = be.find_arb(v)
         D, L = be.trades()
-        psi_f, acc_f = be.eval(v)
+        psi_b, acc_b = be.eval(v)     # consecutive sweeps walk the tiles in alternating directions (option "alternate"):
+        psi_f, acc_f = be.eval(v)     # the next one is backwards, the one after it forwards again
         Do, Lo, psi_o, acc_o = oracle_sweep(batches, n, v, nthreads=8)
         assert rel_to_max(psi, psi_o) <= 1e-12 and abs(acc - acc_o) <= 1e-12 * abs(acc_o)
-        np.testing.assert_array_equal(psi_f, psi)
+        np.testing.assert_array_equal(psi_f, psi)                         # same direction: fused == materialising, bit for bit
+        assert acc_f == acc
+        assert rel_to_max(psi_b, psi) <= 1e-14 and abs(acc_b - acc) <= 1e-13 * abs(acc)   # other direction: rounding only
         g0, g1 = 300_000, 500_001
         np.testing.assert_array_equal(D[:g0], Do[:g0])
         np.testing.assert_array_equal(L[:g0], Lo[:g0])
@@ -226,3 +229,31 @@ def test_determinism_claim_is_conditional_on_private_bin_copies():
                     assert rel_to_max(psi, runs[0][0]) <= 1e-14 and abs(acc - runs[0][1]) <= 1e-13 * abs(acc)
         finally:
             be.close()
+
+
+def test_alternating_tile_direction_is_rounding_only():
+    """Option "alternate" (default 1): consecutive sweeps walk every lane's tiles in alternating directions so that a
+    sweep starts on the pool data the previous one left in the XCD's L2.  Same direction => same bits; opposite
+    direction => summation-order rounding; trades are bit-identical either way; alternate = 0 => every sweep equal."""
+    n = 256
+    batches = [synth.product_pools(400_000, n, seed=101), synth.geomean_pools(300_000, n, seed=102)]
+    v = synth.sweep_prices(n, seed=103)
+    be = cr.DeviceBackend(n, batches)
+    try:
+        runs = []
+        for _ in range(4):
+            psi, acc = be.find_arb(v)
+            runs.append((psi, acc, be.trades()))
+        np.testing.assert_array_equal(runs[0][0], runs[2][0])
+        np.testing.assert_array_equal(runs[1][0], runs[3][0])
+        assert runs[0][1] == runs[2][1] and runs[1][1] == runs[3][1]
+        assert rel_to_max(runs[1][0], runs[0][0]) <= 1e-14
+        for k in (1, 2, 3):
+            np.testing.assert_array_equal(runs[k][2][0], runs[0][2][0])    # Δ
+            np.testing.assert_array_equal(runs[k][2][1], runs[0][2][1])    # Λ
+        be.ctx.set_option("alternate", 0)
+        a, b = be.eval(v), be.eval(v)
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1] == b[1]
+    finally:
+        be.close()

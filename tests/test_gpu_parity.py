@@ -586,7 +586,8 @@ def test_full_size_config3_all_rows():
     be = cr.DeviceBackend(n, [bp, bg])
     psi, acc = be.find_arb(v)
     D, L = be.trades()
-    psi_f, acc_f = be.eval(v)                                           # the fused evaluation route! uses
+    be.eval(v)                                                          # (tile direction alternates between sweeps)
+    psi_f, acc_f = be.eval(v)                                           # the fused evaluation route! uses, same direction
     be.close()
     Do, Lo, psi_o, acc_o = oracle_sweep([bp, bg], n, v, nthreads=_threads())
     np.testing.assert_array_equal(D[:h], Do[:h])                       # ProductTwoCoin half: bit-exact
