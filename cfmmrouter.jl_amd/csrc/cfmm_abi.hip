@@ -161,8 +161,8 @@ struct cfmm_ctx {
     int64_t opt_wave_split = 0;    // 1: fused launches deal each block's wavefronts to the pool families (every block sweeps every segment)
     int64_t opt_xcd_map = 1;       // fused launches: 1 = XCD-aware block -> segment map weighted by pools x cost per pool,
                                    // 2 = XCD-aware with equal cost per pool, 0 = block b -> segment b % nseg
-    int64_t opt_cost_geomean = 18; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one
-    int64_t opt_cost_univ3 = 14;
+    int64_t opt_cost_geomean = 10; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one (10 = blocks in
+    int64_t opt_cost_univ3 = 10;   // proportion to pool counts: measured best once sweeps alternate direction; 18 / 14 before)
     int64_t opt_alternate = 1;     // 1: consecutive sweeps walk the tiles in alternating directions (L2 reuse across sweeps);
                                    //    results of two sweeps at the same v then agree to rounding, not bit for bit
     uint64_t sweep_count = 0;
@@ -251,13 +251,16 @@ int check_two_coin(cfmm_ctx* c, int64_t m, const double* R, const double* gamma,
     return CFMM_OK;
 }
 
-// Grid cap for the fat (512/1024-thread) blocks: a full machine of resident threads while the
-// partial rows are short; half of that (one 1024-thread block per CU) once a row is long enough
-// (n_tokens > 1024) for rows x n_tokens to dominate the fold kernel (measured at n = 4096:
-// fold 10.5 us at 512 rows, 7.8 us at 256; sweep time equal).
+// Grid cap for the fat (512/1024-thread) blocks: HALF a machine of resident threads -- one 1024-thread block
+// (16 wavefronts) per CU.  Round 1 ran a full machine (two blocks per CU); with consecutive sweeps walking the
+// tiles in alternating directions (option "alternate") fewer, longer lanes win: each lane owns 2x the tiles, so
+// more of a sweep starts on L2-resident data, and there are half as many partial rows and LDS prologues
+// (measured, sweep span us at 256 / 384 / 512 blocks: product1m 9.7 / 10.6 / 10.6, config5 19.1 / 22.6 / 21.7,
+// config-4 shard 7.1 / - / 8.1; 128 blocks: 14.9 / 24.5 / 9.2).
 int fat_grid_cap(const cfmm_ctx* c, int block)
 {
-    return (c->n > 1024 && c->n <= kMaxLdsTokens ? kResidentThreads / 2 : kResidentThreads) / block;
+    (void)c;
+    return kResidentThreads / 2 / block;
 }
 
 // Fused multi-family launches: 512 blocks of 512 threads in total measured best on config3
@@ -303,7 +306,7 @@ int64_t family_cost(const cfmm_ctx* c, const Segment& s)
     switch (s.kind) {
     case CFMM_KIND_PRODUCT: return 10;
     case CFMM_KIND_GEOMEAN: return c->opt_cost_geomean;
-    default: return c->opt_cost_univ3 + (s.m > 0 ? 2 * (s.n_ticks_total / s.m) : 0);   // deeper ladders walk longer
+    default: return c->opt_cost_univ3 + (s.m > 0 && s.n_ticks_total / s.m > 2 ? 2 * (s.n_ticks_total / s.m) : 0);   // deeper ladders walk longer
     }
 }
 

@@ -94,7 +94,7 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * log-space form; both are within 1e-12 of the reference), "xcd_map" (fused launches: 1 = default, XCD-aware
  * block -> segment map weighted by pools x cost per pool; 2 = XCD-aware with equal cost per pool; 0 = block b ->
  * segment b % nseg), "cost_geomean" / "cost_univ3" (cost of one evaluation in tenths of a ProductTwoCoin one, used
- * by that map; defaults 18 / 14), "wave_split" (default 0; 1 = every block of a fused launch sweeps every segment,
+ * by that map; defaults 10 / 10 = blocks in proportion to pool counts), "wave_split" (default 0; 1 = every block of a fused launch sweeps every segment,
  * its wavefronts dealt to the families), "alternate" (default 1: consecutive sweeps walk every lane's tiles in
  * alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's L2 -- two sweeps
  * at the same v then agree to summation-order rounding (trades: bit for bit), every second one bit for bit; 0: always
