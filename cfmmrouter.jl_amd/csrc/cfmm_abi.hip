@@ -63,6 +63,9 @@ struct Segment {
     int grid = 0;
     int unroll = 1;
     int64_t row_off = 0; // first partial row
+    PackedFeeTok* pk = nullptr;     // two-coin families: {i1 | i2 << 16, fee-table index} per pool, or null (too many distinct fees)
+    std::vector<double> gvals;      // the segment's distinct fees, in order of first appearance (index = PackedFeeTok::gidx)
+    int gbase = 0;                  // first entry of this segment in its launch's fee table (ensure_geometry)
     std::vector<int32_t> h_ai; // host copy of Ai: large-market mode (incidence build) and UniV3 segments
     // UniV3 only: the pool definitions as uploaded (update_reserves! moves current_price and re-derives the constants)
     std::vector<double> h_cp, h_gamma, h_lt, h_liq;
@@ -76,6 +79,7 @@ struct Group {
     int block = kSmallBlock;
     int grid = 0;       // total blocks of the launch
     int64_t row_off = 0;
+    int gtab_n = 0;     // entries of this launch's fee table (0: its segments use the plain gamma / Ai arrays)
     // XCD-aware weighted block -> segment map of a fused launch (see sweep_multi); xcd_map == false: block b -> segment b % nseg
     bool xcd_map = false;
     unsigned char pattern[32] = {0}, rank[32] = {0};
@@ -136,6 +140,8 @@ struct cfmm_ctx {
     long long peer_timeout_ticks = 3000000000ll;   // 30 s of wall_clock64() at 100 MHz (CFMM_AMD_PEER_TIMEOUT_S)
     double* h_stage = nullptr;    // pinned + device-mapped: [n] v in, [n+1] out, then one uint64 completion flag
     double* d_stage = nullptr;    // device address of h_stage
+    double* d_gtab = nullptr;     // [groups][kMaxFeeTable] fee tables of the launches (packed pool records)
+    size_t gtab_cap = 0;
     unsigned* d_sync = nullptr;   // [kSyncWords] arrival counters of the in-launch fold (zero between launches)
     uint64_t flag_seq = 0;        // host-visible completion flag: value the NEXT flagged sweep will raise
     bool last_inline = false;     // the latest enqueue_sweep folded inside the sweep launch
@@ -163,6 +169,8 @@ struct cfmm_ctx {
                                    // 2 = XCD-aware with equal cost per pool, 0 = block b -> segment b % nseg
     int64_t opt_cost_geomean = 10; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one (10 = blocks in
     int64_t opt_cost_univ3 = 10;   // proportion to pool counts: measured best once sweeps alternate direction; 18 / 14 before)
+    int64_t opt_pack = 1;          // 1: sweeps read the packed fee + token record (24 / 48 B per pool instead of 32 / 56) when the
+                                   //    launch's distinct fees fit the LDS fee table
     int64_t opt_alternate = 1;     // 1: consecutive sweeps walk the tiles in alternating directions (L2 reuse across sweeps);
                                    //    results of two sweeps at the same v then agree to rounding, not bit for bit
     uint64_t sweep_count = 0;
@@ -223,13 +231,55 @@ int upload(cfmm_ctx* c, T** dst, const void* src, size_t count)
 void free_segment(Segment& s)
 {
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
-    (void)hipFree(s.eta); (void)hipFree(s.lR);
+    (void)hipFree(s.eta); (void)hipFree(s.lR); (void)hipFree(s.pk);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
     (void)hipFree(s.pg); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
     s = Segment{};
 }
 
 bool finite_pos(double x) { return std::isfinite(x) && x > 0.0; }
+
+bool global_bins(const cfmm_ctx* c);
+
+// Packed fee + token record of a two-coin segment (sweep.h PackedFeeTok): built when the token ids fit 16 bits and the
+// segment has at most kMaxFeeTable distinct fees; otherwise the segment keeps pk == null and sweeps read gamma / Ai.
+int build_packed(cfmm_ctx* c, Segment& s, int64_t m, const double* gamma, const int32_t* Ai)
+{
+    s.pk = nullptr;
+    s.gvals.clear();
+    if (global_bins(c) || c->n > 65536 || m == 0) return CFMM_OK;
+    std::vector<PackedFeeTok> pk((size_t)m);
+    std::vector<double> vals;
+    uint64_t last_bits = 0;
+    uint32_t last_idx = 0;
+    bool have_last = false;
+    for (int64_t i = 0; i < m; ++i) {
+        uint64_t bits;
+        std::memcpy(&bits, &gamma[i], sizeof bits);
+        uint32_t idx;
+        if (have_last && bits == last_bits) {
+            idx = last_idx;
+        } else {
+            idx = (uint32_t)vals.size();
+            for (uint32_t k = 0; k < (uint32_t)vals.size(); ++k) {   // <= 256 entries: a linear scan beats a hash map
+                uint64_t vb;
+                std::memcpy(&vb, &vals[k], sizeof vb);
+                if (vb == bits) { idx = k; break; }
+            }
+            if (idx == (uint32_t)vals.size()) {
+                if ((int)vals.size() == kMaxFeeTable) return CFMM_OK;   // too many fee tiers: stay unpacked
+                vals.push_back(gamma[i]);
+            }
+            last_bits = bits; last_idx = idx; have_last = true;
+        }
+        pk[(size_t)i].tok = (uint32_t)Ai[2 * i] | ((uint32_t)Ai[2 * i + 1] << 16);
+        pk[(size_t)i].gidx = idx;
+    }
+    int rc = upload(c, &s.pk, pk.data(), (size_t)m);
+    if (rc != CFMM_OK) return rc;
+    s.gvals.swap(vals);
+    return CFMM_OK;
+}
 
 // What two_coin_check_cast (src/cfmms.jl:76-90) enforces structurally is implied by the [m][2]
 // layout; here we check the values the closed forms assume.
@@ -368,7 +418,7 @@ int bin_copies(const cfmm_ctx* c, int block)
     if (global_bins(c)) return 1;
     const int waves = block / 64;
     if (c->opt_bin_copies == 1) return 1;
-    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block, 1);   // incl. the log-price row GeometricMean launches stage
+    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block, 1, kMaxFeeTable);   // incl. the log-price row and the fee table a launch may stage
     if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
     // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
     return per_wave <= (block == kBigBlock ? 80 : (block == kMidBlock ? 48 : 32)) * 1024 ? waves : 1;
@@ -467,6 +517,42 @@ int ensure_geometry(cfmm_ctx* c)
             c->groups.push_back(g);
         }
     }
+    // fee tables of the launches: the packed records of a launch's segments index ONE table staged in LDS
+    {
+        std::vector<double> tabs(c->groups.size() * (size_t)kMaxFeeTable, 1.0);
+        for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+            Group& g = c->groups[gi];
+            int total = 0;
+            bool ok = c->opt_pack != 0 && !global_bins(c);
+            for (int k = 0; k < g.nseg && ok; ++k) {
+                const Segment& sg = c->segs[(size_t)g.first + k];
+                if (sg.kind == CFMM_KIND_UNIV3) continue;
+                if (!sg.pk) ok = false;
+                total += (int)sg.gvals.size();
+            }
+            g.gtab_n = ok && total <= kMaxFeeTable ? total : 0;
+            if (g.gtab_n == 0) continue;
+            int base = 0;
+            for (int k = 0; k < g.nseg; ++k) {
+                Segment& sg = c->segs[(size_t)g.first + k];
+                if (sg.kind == CFMM_KIND_UNIV3) continue;
+                sg.gbase = base;
+                std::copy(sg.gvals.begin(), sg.gvals.end(), tabs.begin() + (std::ptrdiff_t)(gi * kMaxFeeTable + (size_t)base));
+                base += (int)sg.gvals.size();
+            }
+        }
+        if (tabs.size() > c->gtab_cap) {
+            (void)hipFree(c->d_gtab);
+            c->d_gtab = nullptr;
+            c->gtab_cap = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_gtab), tabs.size() * sizeof(double)));
+            c->gtab_cap = tabs.size();
+        }
+        if (!tabs.empty()) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(c->d_gtab, tabs.data(), tabs.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     c->rows_total = rows;
     c->m_total = trades;
     if (rows > c->rows_cap) {
@@ -520,11 +606,15 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     c->last_inline = inline_fold;
     c->last_flagged = flagged;
     HIP_TRY(c, hipSetDevice(c->device));
+    size_t group_index = 0;
     for (const Group& g : c->groups) {
+        const size_t gi = group_index++;
         SweepArgs a;
         a.v = d_v;
         a.n = c->n;
         a.n_pad = c->n_pad;
+        a.gtab = c->d_gtab ? c->d_gtab + gi * kMaxFeeTable : nullptr;
+        a.gtab_n = a.gtab ? g.gtab_n : 0;
         a.need_logv = 0;
         if (!gb && c->opt_geomean_exact == 0)
             for (int k = 0; k < g.nseg; ++k)
@@ -541,7 +631,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.fold_out = d_out;
         a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
         a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
-        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv);
+        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
             ea = take_event(c);
@@ -569,8 +659,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
                 ms.gflow = gb ? c->d_flow + s.trade_off : nullptr;
                 switch (s.kind) {
-                case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai}; break;
-                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact}; break;
+                case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
+                case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
                 default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
                 }
             }
@@ -584,9 +674,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
             LaunchCfg cfg{g.block, g.grid, s.unroll, lds, ea, eb};
             switch (s.kind) {
-            case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai}, a, cfg, materialize, c->stream); break;
+            case CFMM_KIND_PRODUCT: e = launch_sweep(ProductPools{s.R, s.gamma, s.Ai, a.gtab_n ? s.pk : nullptr, s.gbase}, a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN:
-                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact}, a, cfg, materialize, c->stream);
+                e = launch_sweep(GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact,
+                                              a.gtab_n && c->opt_geomean_exact == 0 ? s.pk : nullptr, s.gbase}, a, cfg, materialize, c->stream);
                 break;
             default:
                 e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}, a, cfg, materialize, c->stream);
@@ -1138,7 +1229,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& s : c->segs) free_segment(s);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials); (void)hipFree(c->d_sync);
+    (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials); (void)hipFree(c->d_sync); (void)hipFree(c->d_gtab);
     (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
     (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
     (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
@@ -1183,6 +1274,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "spin_wait")) return &c->opt_spin_wait;
     if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
     if (!std::strcmp(key, "alternate")) return &c->opt_alternate;
+    if (!std::strcmp(key, "pack")) return &c->opt_pack;
     if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
     if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;
     if (!std::strcmp(key, "cost_univ3")) return &c->opt_cost_univ3;
@@ -1211,7 +1303,7 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
             if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
         }
     if (slot == &c->opt_max_grid || slot == &c->opt_unroll || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
-        slot == &c->opt_geomean_exact || slot == &c->opt_univ3_coop || slot == &c->opt_xcd_map || slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
+        slot == &c->opt_geomean_exact || slot == &c->opt_univ3_coop || slot == &c->opt_pack || slot == &c->opt_xcd_map || slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
         c->geometry_dirty = true;
     return CFMM_OK;
 }
@@ -1239,7 +1331,7 @@ int cfmm_pools_add_product(cfmm_ctx* c, int64_t m, const double* R, const double
     s.kind = CFMM_KIND_PRODUCT;
     s.m = m;
     if ((rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.gamma, gamma, (size_t)m)) ||
-        (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
+        (rc = upload(c, &s.Ai, Ai, (size_t)m)) || (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;
     }
@@ -1275,7 +1367,8 @@ int cfmm_pools_add_geomean(cfmm_ctx* c, int64_t m, const double* R, const double
     s.m = m;
     if ((rc = upload(c, &s.eta, etas.data(), (size_t)m)) || (rc = upload(c, &s.lR, lR.data(), (size_t)m)) ||
         (rc = upload(c, &s.R, R, (size_t)m)) || (rc = upload(c, &s.w, w, (size_t)m)) ||
-        (rc = upload(c, &s.gamma, gamma, (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m))) {
+        (rc = upload(c, &s.gamma, gamma, (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
+        (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;
     }

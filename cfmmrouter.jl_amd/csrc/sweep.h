@@ -17,10 +17,21 @@ constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 
 constexpr int kGatherChunk = 512;    // incidence entries per wavefront in gather_chunks
 
 // SoA-of-pairs pool stores, one struct per pool family.  All pointers are device pointers.
+// Packed fee + token-index record (8 B instead of 16): tok = i1 | i2 << 16 (n_tokens <= 65536), gidx = index of
+// the pool's fee in the launch's fee table (markets use a handful of fee tiers; the table, <= kMaxFeeTable distinct
+// values per launch, is staged in LDS).  Segments whose fees do not fit keep the plain gamma / Ai arrays (pk == null).
+struct PackedFeeTok {
+    uint32_t tok;
+    uint32_t gidx;
+};
+constexpr int kMaxFeeTable = 256;
+
 struct ProductPools {            // src/cfmms.jl:101-111
     const double2* R;            // [m] {R1, R2}
     const double* gamma;         // [m]
     const int2* Ai;              // [m] {i1, i2}, 0-based
+    const PackedFeeTok* pk;      // [m] or null: replaces gamma + Ai in the sweep (24 B per pool instead of 32)
+    int gbase;                   // this segment's first entry in the launch's fee table
 };
 struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* R;
@@ -31,6 +42,8 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* Q;            // [m] {Q1, Q2}: the v-independent part of the two log-space exponents, prepared at
                                  //     upload: Q1 = log γ + log η + log R2 + η·log R1,  Q2 = η·(log γ + log R1 − log η) + log R2
     int reference_order;         // 1: evaluate with pow in the reference's operation order
+    const PackedFeeTok* pk;      // [m] or null: replaces gamma + Ai in the log-space sweep (48 B per pool instead of 56)
+    int gbase;
 };
 struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
     const double2* pg;           // [m] {current_price, gamma}
@@ -51,6 +64,8 @@ struct SweepArgs {
     int n;                       // n_tokens
     int n_pad;                   // n rounded up to even (LDS row pitch)
     int need_logv;               // 1: also stage log v per token in LDS (launches with a log-space GeometricMean segment)
+    const double* gtab;          // the launch's fee table (device), staged in LDS when gtab_n > 0
+    int gtab_n;
     int copies;                  // private bin copies per block (1 or one per wavefront)
     int64_t m;                   // pools in this segment
     double2* Delta;              // [m] segment base, may be null when !materialize
@@ -161,7 +176,7 @@ hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
                                   double2* Q, const double* eta, int64_t m, hipStream_t s);
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv = 0);
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv = 0, int gtab_n = 0);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 
 } // namespace cfmm

@@ -58,7 +58,20 @@ struct ProductOps {
         int2 ai;
     };
     ProductPools p;
-    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.gamma[i], p.Ai[i]}; }
+    __device__ __forceinline__ Raw load(int64_t i) const
+    {
+        if (p.pk) {   // packed record: the fee arrives as a table index (carried in g's bits until resolve())
+            const PackedFeeTok k = p.pk[i];
+            return Raw{p.R[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx)),
+                       make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16))};
+        }
+        return Raw{p.R[i], p.gamma[i], p.Ai[i]};
+    }
+    // after stage_prices(): look the fee up in the LDS table
+    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    {
+        if (p.pk) r.g = gtab_lds[__double_as_longlong(r.g)];
+    }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // All four closed forms exactly as written in the reference (:134-138).
     __device__ __forceinline__ void solve_full(double R1, double R2, double g, double v1, double v2, Trade& t) const
@@ -129,6 +142,7 @@ struct GeoMeanOps {
     };
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i]}; }
+    __device__ __forceinline__ void resolve(Raw&, const double*) const {}
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // Same idea as ProductOps::solve: Δ₁,Λ₂ > 0 ⇔ γ·m₁₂·η·R₂ > R₁ and Δ₂,Λ₁ > 0 ⇔ γ·m₂₁·R₁/η > R₂
     // (the bases of :180 exceed r2^(η+1)); only the live direction's two forms (4 pow instead of
@@ -188,7 +202,16 @@ struct GeoMeanLogOps {
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
+        if (p.pk) {
+            const PackedFeeTok k = p.pk[i];
+            return Raw{p.R[i], p.Q[i], p.eta[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx)),
+                       make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16))};
+        }
         return Raw{p.R[i], p.Q[i], p.eta[i], p.gamma[i], p.Ai[i]};
+    }
+    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    {
+        if (p.pk) r.g = gtab_lds[__double_as_longlong(r.g)];
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // dlv = log v2 − log v1
@@ -250,6 +273,7 @@ struct UniV3Ops {
     {
         return Raw{p.pg[i], p.cur_a[i], p.cur_b[i], p.cur_c[i], p.Ai[i], p.walk[i], i};
     }
+    __device__ __forceinline__ void resolve(Raw&, const double*) const {}
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
 
     // find_arb_pos (:321-337) on one prepared walk-list entry
@@ -462,6 +486,7 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 struct SweepLds {
     double* v_lds;     // [n_pad]
     double* lv_lds;    // [n_pad] log v (only when a.need_logv)
+    double* gtab;      // [gtab_n] the launch's fee table (packed pool records)
     double* bins;      // [copies][n_pad]
     double* wsum;      // [kWaves]
     double* my_bins;   // this wavefront's copy
@@ -476,6 +501,7 @@ __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
     L.lv_lds = lds + a.n_pad;
     L.bins = lds + (GBINS ? 0 : (a.need_logv ? 2 : 1) * a.n_pad);
     L.wsum = GBINS ? lds : L.bins + (size_t)a.copies * a.n_pad;
+    L.gtab = L.wsum + BLOCK / 64;
     L.my_bins = L.bins + (size_t)(a.copies == 1 ? 0 : (threadIdx.x >> 6)) * a.n_pad;
     return L;
 }
@@ -494,6 +520,8 @@ __device__ __forceinline__ void stage_prices(const SweepArgs& a, const SweepLds&
         if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
     }
     for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+    if (!GBINS)
+        for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
     __syncthreads();
 }
 
@@ -509,7 +537,9 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     double acc = 0.0;
     // `valid` is false only for wave-cooperative families, whose lanes without a pool still have to
     // take part in the wavefront-wide phases of solve_wave.
-    auto process = [&](const typename Ops::Raw& raw, int64_t i, bool valid) {
+    auto process = [&](const typename Ops::Raw& raw_in, int64_t i, bool valid) {
+        typename Ops::Raw raw = raw_in;
+        if constexpr (!GBINS) ops.resolve(raw, L.gtab);   // packed records: fee table index -> fee
         int2 tok = make_int2(0, 0);
         if (valid) tok = ops.tokens(raw);
         double v1, v2;                                   // v[r.cfmms[i].Ai]
@@ -1021,10 +1051,10 @@ static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEve
     else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
 }
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv)
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab_n)
 {
     // the fold blocks of the same launch need [block/64][kReduceCols] doubles + one flag word
-    const size_t sweep = (size_t)n_pad * ((need_logv ? 2 : 1) + copies) + block / 64;
+    const size_t sweep = (size_t)n_pad * ((need_logv ? 2 : 1) + copies) + block / 64 + (size_t)gtab_n;
     const size_t fold = (size_t)(block / 64) * kReduceCols + 2;
     return (sweep > fold ? sweep : fold) * sizeof(double);
 }

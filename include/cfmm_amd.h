@@ -98,7 +98,9 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * its wavefronts dealt to the families), "alternate" (default 1: consecutive sweeps walk every lane's tiles in
  * alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's L2 -- two sweeps
  * at the same v then agree to summation-order rounding (trades: bit for bit), every second one bit for bit; 0: always
- * forwards, every sweep bit-identical).  Unknown keys are CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
+ * forwards, every sweep bit-identical), "pack" (default 1: sweeps read an 8-byte {token pair, fee-table index} record
+ * instead of gamma + Ai when a launch's distinct fees fit a 256-entry table; same results).  Unknown keys are
+ * CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
  * is set to 1 when the library is loaded unless already set (kernel arguments in device memory: -10 % per step);
  * CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */
 int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);

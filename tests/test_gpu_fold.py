@@ -257,3 +257,32 @@ def test_alternating_tile_direction_is_rounding_only():
         assert a[1] == b[1]
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("n_fees", [1, 2, 256, 257, 5000])
+def test_packed_fee_token_records(n_fees):
+    """Sweeps read an 8-byte {i1 | i2 << 16, fee-table index} record instead of gamma + Ai when a launch's distinct fees
+    fit the 256-entry LDS table (option "pack"); markets with more fee tiers fall back to the plain arrays.  Same bits."""
+    n = 300
+    rng = np.random.default_rng(n_fees)
+    fees = np.sort(rng.uniform(0.9, 1.0, n_fees))
+    bp, bg = synth.product_pools(150_000, n, seed=111), synth.geomean_pools(90_000, n, seed=112)
+    bp.γ[:] = fees[rng.integers(0, n_fees, len(bp))]
+    bg.γ[:] = fees[rng.integers(0, n_fees, len(bg))]
+    v = synth.sweep_prices(n, seed=113)
+    res = {}
+    for pack in (1, 0):
+        be = cr.DeviceBackend(n, [bp, bg])
+        be.ctx.set_option("pack", pack)
+        try:
+            psi, acc = be.find_arb(v)
+            res[pack] = (psi, acc) + be.trades()
+        finally:
+            be.close()
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    assert res[1][1] == res[0][1]
+    np.testing.assert_array_equal(res[1][2], res[0][2])
+    np.testing.assert_array_equal(res[1][3], res[0][3])
+    Do, Lo, psi_o, acc_o = oracle_sweep([bp, bg], n, v, nthreads=8)
+    assert rel_to_max(res[1][0], psi_o) <= 1e-12
+    np.testing.assert_array_equal(res[1][2][:len(bp)], Do[:len(bp)])
