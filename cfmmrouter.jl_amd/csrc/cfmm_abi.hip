@@ -50,6 +50,8 @@ struct Segment {
     double* gamma = nullptr;
     int2* Ai = nullptr;
     double2* pg = nullptr;
+    double* cp = nullptr;    // univ3: current_price alone (packed records)
+    int has_walk = 1;        // univ3: some pool has a tick beyond its current one
     double2* cur_a = nullptr;
     double2* cur_b = nullptr;
     double* cur_c = nullptr;
@@ -233,7 +235,7 @@ void free_segment(Segment& s)
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
     (void)hipFree(s.eta); (void)hipFree(s.lR); (void)hipFree(s.pk);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
-    (void)hipFree(s.pg); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
+    (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
     s = Segment{};
 }
 
@@ -526,7 +528,6 @@ int ensure_geometry(cfmm_ctx* c)
             bool ok = c->opt_pack != 0 && !global_bins(c);
             for (int k = 0; k < g.nseg && ok; ++k) {
                 const Segment& sg = c->segs[(size_t)g.first + k];
-                if (sg.kind == CFMM_KIND_UNIV3) continue;
                 if (!sg.pk) ok = false;
                 total += (int)sg.gvals.size();
             }
@@ -535,7 +536,6 @@ int ensure_geometry(cfmm_ctx* c)
             int base = 0;
             for (int k = 0; k < g.nseg; ++k) {
                 Segment& sg = c->segs[(size_t)g.first + k];
-                if (sg.kind == CFMM_KIND_UNIV3) continue;
                 sg.gbase = base;
                 std::copy(sg.gvals.begin(), sg.gvals.end(), tabs.begin() + (std::ptrdiff_t)(gi * kMaxFeeTable + (size_t)base));
                 base += (int)sg.gvals.size();
@@ -661,7 +661,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
                 case CFMM_KIND_GEOMEAN: ms.pools.g = GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
-                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}; break;
+                default: ms.pools.u = UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0), s.has_walk, s.cp, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
                 }
             }
             LaunchCfg cfg{g.block, g.grid, 1, lds, ea, eb};
@@ -680,7 +680,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                                               a.gtab_n && c->opt_geomean_exact == 0 ? s.pk : nullptr, s.gbase}, a, cfg, materialize, c->stream);
                 break;
             default:
-                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0)}, a, cfg, materialize, c->stream);
+                e = launch_sweep(UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout, c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0), s.has_walk, s.cp, a.gtab_n ? s.pk : nullptr, s.gbase}, a, cfg, materialize, c->stream);
                 break;
             }
         }
@@ -1098,12 +1098,14 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
     s.m = m;
     s.n_ticks_total = T;
     s.deep = longest > 8 ? 1 : 0; // short ladders: a lane walks its own pool; long: the wavefront helps
+    s.has_walk = longest > 0 ? 1 : 0;
     int rc;
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
         (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
         (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
         (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
-        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size()))) {
+        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size())) ||
+        (rc = upload(c, &s.cp, current_price, (size_t)m)) || (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;
     }
@@ -1563,7 +1565,9 @@ int cfmm_update_reserves(cfmm_ctx* c)
         (void)hipFree(s.pg); (void)hipFree(s.Ai); (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c);
         (void)hipFree(s.curR); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
         s.pg = ns.pg; s.Ai = ns.Ai; s.cur_a = ns.cur_a; s.cur_b = ns.cur_b; s.cur_c = ns.cur_c; s.curR = ns.curR;
-        s.walk = ns.walk; s.ks = ns.ks; s.dt = ns.dt; s.rout = ns.rout; s.deep = ns.deep;
+        s.walk = ns.walk; s.ks = ns.ks; s.dt = ns.dt; s.rout = ns.rout; s.deep = ns.deep; s.has_walk = ns.has_walk;
+        (void)hipFree(s.cp); (void)hipFree(s.pk);
+        s.cp = ns.cp; s.pk = ns.pk; s.gvals.swap(ns.gvals);
         s.h_cp.swap(cp);
     }
     c->have_trades = false;   // consumed: the trades no longer describe an arbitrage of the stored pools

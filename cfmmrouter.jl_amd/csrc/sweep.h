@@ -57,6 +57,11 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     const double2* dt;           // [W] {delta_max, R_out + beta_out}
     const double* rout;          // [W] R_out
     int deep;                    // 1: some walk list is long -> wavefront-cooperative kernel (UniV3CoopOps)
+    int has_walk;                // 0: no pool of the segment has a tick beyond its current one (every BoundedProduct
+                                 //    pool): the walk spans are not even loaded
+    const double* cp;            // [m] current_price alone, read with pk instead of pg + Ai (packed records)
+    const PackedFeeTok* pk;      // [m] or null
+    int gbase;
 };
 
 struct SweepArgs {

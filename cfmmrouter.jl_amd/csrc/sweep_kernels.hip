@@ -271,9 +271,18 @@ struct UniV3Ops {
     UniV3Pools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        return Raw{p.pg[i], p.cur_a[i], p.cur_b[i], p.cur_c[i], p.Ai[i], p.walk[i], i};
+        const int4 walk = p.has_walk ? p.walk[i] : make_int4(0, 0, 0, 0);
+        if (p.pk) {   // packed record: price alone + {tokens, fee-table index}
+            const PackedFeeTok k = p.pk[i];
+            return Raw{make_double2(p.cp[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx))), p.cur_a[i], p.cur_b[i],
+                       p.cur_c[i], make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16)), walk, i};
+        }
+        return Raw{p.pg[i], p.cur_a[i], p.cur_b[i], p.cur_c[i], p.Ai[i], walk, i};
     }
-    __device__ __forceinline__ void resolve(Raw&, const double*) const {}
+    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    {
+        if (p.pk) r.pg.y = gtab_lds[__double_as_longlong(r.pg.y)];
+    }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
 
     // find_arb_pos (:321-337) on one prepared walk-list entry
