@@ -124,8 +124,18 @@ struct cfmm_ctx {
     double* d_out = nullptr;      // [n+1]
     double* d_partials = nullptr; // [rows_cap][n+1]
     int64_t rows_cap = 0;
-    double2* d_delta = nullptr;   // [trade_cap]
+    // trade buffers [trade_cap] each.  Compact layout (option "compact_trades", default): d_delta holds ONE 16-byte
+    // record per pool, d_lambda / d_over the four values of the rare pools that trade in both directions (sweep.h
+    // SweepArgs); plain layout: d_delta = {Δ₁, Δ₂}, d_lambda = {Λ₁, Λ₂}.  d_xdelta / d_xlambda: expanded copies, only for
+    // cfmm_trades_dev.
+    double2* d_delta = nullptr;
     double2* d_lambda = nullptr;
+    double2* d_over = nullptr;
+    double2* d_xdelta = nullptr;
+    double2* d_xlambda = nullptr;
+    int64_t x_cap = 0;
+    int trades_compact = 0;       // layout of the trades currently on the device
+    std::vector<double2> h_rec, h_ovA, h_ovB;   // host scratch of cfmm_get_trades*
     int64_t trade_cap = 0;
     // large-market mode (n > kMaxLdsTokens): token -> (pool, side) incidence and flow scratch
     double2* d_flow = nullptr;    // [m_total] {Λ₁−Δ₁, Λ₂−Δ₂}
@@ -171,6 +181,8 @@ struct cfmm_ctx {
                                    // 2 = XCD-aware with equal cost per pool, 0 = block b -> segment b % nseg
     int64_t opt_cost_geomean = 10; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one (10 = blocks in
     int64_t opt_cost_univ3 = 10;   // proportion to pool counts: measured best once sweeps alternate direction; 18 / 14 before)
+    int64_t opt_compact_trades = 1; // 1: a materialising sweep writes one 16-byte trade record per pool (+ overflow rows for the rare
+                                   //    pools trading in both directions) instead of 32 bytes; lossless, see sweep.h SweepArgs
     int64_t opt_pack = 1;          // 1: sweeps read the packed fee + token record (24 / 48 B per pool instead of 32 / 56) when the
                                    //    launch's distinct fees fit the LDS fee table
     int64_t opt_alternate = 1;     // 1: consecutive sweeps walk the tiles in alternating directions (L2 reuse across sweeps);
@@ -563,11 +575,12 @@ int ensure_geometry(cfmm_ctx* c)
         c->rows_cap = rows;
     }
     if (trades > c->trade_cap) {
-        (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
-        c->d_delta = c->d_lambda = nullptr;
+        (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda); (void)hipFree(c->d_over);
+        c->d_delta = c->d_lambda = c->d_over = nullptr;
         c->trade_cap = 0;
         HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_delta), (size_t)trades * sizeof(double2)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_lambda), (size_t)trades * sizeof(double2)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_over), (size_t)trades * sizeof(double2)));
         c->trade_cap = trades;
     }
     if (global_bins(c)) {
@@ -621,7 +634,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 if (c->segs[(size_t)g.first + k].kind == CFMM_KIND_GEOMEAN) a.need_logv = 1;
         a.copies = bin_copies(c, g.block);
         a.m = 0;
-        a.Delta = a.Lambda = nullptr;
+        a.Delta = a.Lambda = a.Over = nullptr;
+        a.compact = (c->opt_compact_trades != 0 && !gb) ? 1 : 0;
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
         a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
@@ -657,6 +671,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.m = s.m;
                 ms.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
                 ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+                ms.Over = materialize ? c->d_over + s.trade_off : nullptr;
                 ms.gflow = gb ? c->d_flow + s.trade_off : nullptr;
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = ProductPools{s.R, s.gamma, s.Ai, a.gtab_n ? s.pk : nullptr, s.gbase}; break;
@@ -671,6 +686,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.m = s.m;
             a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
+            a.Over = materialize ? c->d_over + s.trade_off : nullptr;
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
             LaunchCfg cfg{g.block, g.grid, s.unroll, lds, ea, eb};
             switch (s.kind) {
@@ -730,7 +746,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (gb || (c->rows_total == 0 && !sharded)) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
-    if (materialize) c->have_trades = true;
+    if (materialize) {
+        c->have_trades = true;
+        c->trades_compact = (c->opt_compact_trades != 0 && !gb) ? 1 : 0;
+    }
     ++c->sweep_count;
     return CFMM_OK;
 }
@@ -1232,7 +1251,8 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     for (auto& s : c->segs) free_segment(s);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(c->d_v); (void)hipFree(c->d_out); (void)hipFree(c->d_partials); (void)hipFree(c->d_sync); (void)hipFree(c->d_gtab);
-    (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda);
+    (void)hipFree(c->d_delta); (void)hipFree(c->d_lambda); (void)hipFree(c->d_over);
+    (void)hipFree(c->d_xdelta); (void)hipFree(c->d_xlambda);
     (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
     (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1277,6 +1297,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "inline_fold")) return &c->opt_inline_fold;
     if (!std::strcmp(key, "alternate")) return &c->opt_alternate;
     if (!std::strcmp(key, "pack")) return &c->opt_pack;
+    if (!std::strcmp(key, "compact_trades")) return &c->opt_compact_trades;
     if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
     if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;
     if (!std::strcmp(key, "cost_univ3")) return &c->opt_cost_univ3;
@@ -1458,6 +1479,42 @@ int cfmm_eval(cfmm_ctx* c, const double* v, double* psi_out, double* acc_out)
     return CFMM_OK;
 }
 
+// D2H of trade rows [row0, row0 + count) of the context's buffers into Delta / Lambda ([count][2] each, may be
+// null), decoding the compact records on the way.
+static int download_trades(cfmm_ctx* c, int64_t row0, int64_t count, double* Delta, double* Lambda)
+{
+    if (count == 0) return CFMM_OK;
+    if (!c->trades_compact) {
+        if (Delta) HIP_TRY(c, hipMemcpy(Delta, c->d_delta + row0, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+        if (Lambda) HIP_TRY(c, hipMemcpy(Lambda, c->d_lambda + row0, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+        return CFMM_OK;
+    }
+    c->h_rec.resize((size_t)count);
+    HIP_TRY(c, hipMemcpy(c->h_rec.data(), c->d_delta + row0, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+    bool any_overflow = false;
+    for (int64_t i = 0; i < count; ++i) {
+        const double2 r = c->h_rec[(size_t)i];
+        double d1 = 0.0, d2 = 0.0, l1 = 0.0, l2 = 0.0;
+        if (r.y == -1.0) any_overflow = true;                         // both directions: fetched below
+        else if (std::signbit(r.x)) { d2 = -r.x; l1 = r.y; }           // {−Δ₂, Λ₁}
+        else { d1 = r.x; l2 = r.y; }                                   // {+Δ₁, Λ₂}
+        if (Delta) { Delta[2 * i] = d1; Delta[2 * i + 1] = d2; }
+        if (Lambda) { Lambda[2 * i] = l1; Lambda[2 * i + 1] = l2; }
+    }
+    if (any_overflow) {
+        c->h_ovA.resize((size_t)count);
+        c->h_ovB.resize((size_t)count);
+        HIP_TRY(c, hipMemcpy(c->h_ovA.data(), c->d_lambda + row0, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_ovB.data(), c->d_over + row0, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < count; ++i) {
+            if (c->h_rec[(size_t)i].y != -1.0) continue;
+            if (Delta) { Delta[2 * i] = c->h_ovA[(size_t)i].x; Delta[2 * i + 1] = c->h_ovA[(size_t)i].y; }
+            if (Lambda) { Lambda[2 * i] = c->h_ovB[(size_t)i].x; Lambda[2 * i + 1] = c->h_ovB[(size_t)i].y; }
+        }
+    }
+    return CFMM_OK;
+}
+
 int cfmm_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t count, double* Delta, double* Lambda)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
@@ -1469,11 +1526,7 @@ int cfmm_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t count
     if (count == 0) return CFMM_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (Delta)
-        HIP_TRY(c, hipMemcpy(Delta, c->d_delta + s.trade_off + first, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
-    if (Lambda)
-        HIP_TRY(c, hipMemcpy(Lambda, c->d_lambda + s.trade_off + first, (size_t)count * sizeof(double2), hipMemcpyDeviceToHost));
-    return CFMM_OK;
+    return download_trades(c, s.trade_off + first, count, Delta, Lambda);
 }
 
 int cfmm_get_trades(cfmm_ctx* c, double* Delta, double* Lambda)
@@ -1492,9 +1545,7 @@ int cfmm_get_trades(cfmm_ctx* c, double* Delta, double* Lambda)
     }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (Delta) HIP_TRY(c, hipMemcpy(Delta, c->d_delta, (size_t)c->m_total * sizeof(double2), hipMemcpyDeviceToHost));
-    if (Lambda) HIP_TRY(c, hipMemcpy(Lambda, c->d_lambda, (size_t)c->m_total * sizeof(double2), hipMemcpyDeviceToHost));
-    return CFMM_OK;
+    return download_trades(c, 0, c->m_total, Delta, Lambda);
 }
 
 int cfmm_netflows(cfmm_ctx* c, double* psi)
@@ -1537,6 +1588,7 @@ int cfmm_update_reserves(cfmm_ctx* c)
     for (Segment& s : c->segs) {
         if (s.kind != CFMM_KIND_UNIV3) {   // R <- R + γΔ − Λ on the device, no host traffic
             hipError_t e = launch_update_two_coin(s.R, s.gamma, c->d_delta + s.trade_off, c->d_lambda + s.trade_off,
+                                                  c->d_over + s.trade_off, c->trades_compact,
                                                   s.kind == CFMM_KIND_GEOMEAN ? s.lR : nullptr, s.eta, s.m, c->stream);
             if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "update launch failed: %s", hipGetErrorString(e));
             continue;
@@ -1637,6 +1689,26 @@ int cfmm_trades_dev(cfmm_ctx* c, const double** d_delta, const double** d_lambda
     CFMM_SINGLE_ONLY(c, "cfmm_trades_dev");
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
+    if (c->opt_compact_trades != 0 && !global_bins(c)) {
+        // device consumers get the reference's layout: the compact records of the latest materialising sweep are
+        // expanded (asynchronously, on the context's stream) into {Δ₁, Δ₂} / {Λ₁, Λ₂} arrays -- call again after
+        // every sweep whose trades are wanted
+        if (c->m_total > c->x_cap) {
+            (void)hipFree(c->d_xdelta); (void)hipFree(c->d_xlambda);
+            c->d_xdelta = c->d_xlambda = nullptr;
+            c->x_cap = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_xdelta), (size_t)c->m_total * sizeof(double2)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_xlambda), (size_t)c->m_total * sizeof(double2)));
+            c->x_cap = c->m_total;
+        }
+        if (c->have_trades && c->trades_compact) {
+            hipError_t e = launch_expand_trades(c->d_delta, c->d_lambda, c->d_over, c->d_xdelta, c->d_xlambda, c->m_total, c->stream);
+            if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "expand launch failed: %s", hipGetErrorString(e));
+        }
+        if (d_delta) *d_delta = reinterpret_cast<const double*>(c->d_xdelta);
+        if (d_lambda) *d_lambda = reinterpret_cast<const double*>(c->d_xlambda);
+        return CFMM_OK;
+    }
     if (d_delta) *d_delta = reinterpret_cast<const double*>(c->d_delta);
     if (d_lambda) *d_lambda = reinterpret_cast<const double*>(c->d_lambda);
     return CFMM_OK;

@@ -73,8 +73,17 @@ struct SweepArgs {
     int gtab_n;
     int copies;                  // private bin copies per block (1 or one per wavefront)
     int64_t m;                   // pools in this segment
-    double2* Delta;              // [m] segment base, may be null when !materialize
+    // Trade buffers of the segment (null when !materialize).  compact == 0: Delta[i] = {Δ₁, Δ₂}, Lambda[i] = {Λ₁, Λ₂}
+    // (32 B written per pool).  compact == 1: at most one direction of a pool trades, so ONE 16-byte record goes
+    // to Delta[i]:  {+Δ₁, Λ₂}  (direction 1 or no trade)  or  {−Δ₂, Λ₁}  (direction 2; the sign bit of the first
+    // entry carries the direction, −0.0 included); any other pool -- both directions non-zero (γ > 1), NaN, or the tiny
+    // negative / −0.0 values the reference's tick arithmetic yields on degenerate UniV3 boundaries -- writes the record
+    // {0, −1} and its four values to Lambda[i] = {Δ₁, Δ₂}, Over[i] = {Λ₁, Λ₂}.  Lossless bit for bit; decoded by
+    // cfmm_get_trades / expand_trades / update_two_coin.
+    double2* Delta;
     double2* Lambda;
+    double2* Over;
+    int compact;
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int nt_stores;               // trade stores: 0 plain, 1 non-temporal, 2 write-through
@@ -109,6 +118,7 @@ struct MultiSeg {
     AnyPools pools;
     double2* Delta;
     double2* Lambda;
+    double2* Over;
     double2* gflow;
 };
 struct MultiArgs {
@@ -179,7 +189,10 @@ hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double
 
 // R <- (R + gamma*Delta) - Lambda in place; GeometricMean (Q, eta non-null): Q <- the exponents' constants for the new R
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  double2* Q, const double* eta, int64_t m, hipStream_t s);
+                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, hipStream_t s);
+// compact trade records -> full {Δ₁, Δ₂} / {Λ₁, Λ₂} arrays (cfmm_trades_dev)
+hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const double2* ovB, double2* Delta, double2* Lambda,
+                                int64_t m, hipStream_t s);
 
 size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv = 0, int gtab_n = 0);
 hipError_t prepare_kernels(size_t max_lds_bytes);

@@ -567,8 +567,33 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         }
         if (!valid) return;
         if (MAT) {
-            store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
-            store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
+            if (a.compact) {   // one 16-byte record per pool (see SweepArgs)
+                // a record can carry one direction whose two values have a clear sign bit (NaN payloads survive the
+                // sign flip) while the other direction is exactly +0; everything else -- both directions trading and
+                // the tiny negative / -0.0 values the reference's tick arithmetic produces on degenerate UniV3
+                // boundaries -- takes the overflow rows, so the encoding is lossless bit for bit
+                const int d1h = __double2hiint(t.d1), d2h = __double2hiint(t.d2), l1h = __double2hiint(t.l1), l2h = __double2hiint(t.l2);
+                const int z1 = d2h | __double2loint(t.d2) | l1h | __double2loint(t.l1);   // 0 <=> Δ₂ and Λ₁ are +0.0
+                const int z2 = d1h | __double2loint(t.d1) | l2h | __double2loint(t.l2);   // 0 <=> Δ₁ and Λ₂ are +0.0
+                const bool dir1 = (z1 == 0) & ((d1h | l2h) >= 0);
+                const bool dir2 = (z2 == 0) & ((d2h | l1h) >= 0);
+                double ra = t.d1, rb = t.l2;
+                if (!dir1) {
+                    if (dir2) {
+                        ra = -t.d2;          // sign bit set (−0.0 included): direction 2
+                        rb = t.l1;
+                    } else {
+                        a.Lambda[i] = make_double2(t.d1, t.d2);
+                        a.Over[i] = make_double2(t.l1, t.l2);
+                        ra = 0.0;
+                        rb = -1.0;
+                    }
+                }
+                store_pair(a.Delta + i, ra, rb, a.nt_stores);
+            } else {
+                store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
+                store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
+            }
         }
         // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
         acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
@@ -853,6 +878,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         a.m = sg.m;
         a.Delta = sg.Delta;
         a.Lambda = sg.Lambda;
+        a.Over = sg.Over;
         a.gflow = sg.gflow;
         const SweepLds L = carve_lds<BLOCK, GBINS>(a);
         stage_prices<BLOCK, GBINS>(a, L);
@@ -901,6 +927,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.m = sg.m;
     a.Delta = sg.Delta;
     a.Lambda = sg.Lambda;
+    a.Over = sg.Over;
     a.gflow = sg.gflow;
     switch (sg.kind) {
     case 0:
@@ -1196,15 +1223,40 @@ hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, 
 // problem prescribes (find_arb! docstring, src/cfmms.jl:26-31): R <- (R + γΔ) − Λ, in place, from
 // the trades of the latest materialising sweep; GeometricMean segments refresh the exponents'
 // v-independent constants {Q1, Q2} (see GeoMeanLogOps) with the same expressions as the upload.
+// one pool's trades from the buffers (plain or compact layout, see SweepArgs)
+__device__ __forceinline__ void read_trade(const double2* __restrict__ Delta, const double2* __restrict__ Lambda,
+                                           const double2* __restrict__ Over, int compact, long long i, double2& d, double2& l)
+{
+    if (!compact) {
+        d = Delta[i];
+        l = Lambda[i];
+        return;
+    }
+    const double2 r = Delta[i];
+    if (r.y == -1.0) {
+        d = Lambda[i];
+        l = Over[i];
+    } else if (__builtin_signbit(r.x)) {
+        d = make_double2(0.0, -r.x);
+        l = make_double2(r.y, 0.0);
+    } else {
+        d = make_double2(r.x, 0.0);
+        l = make_double2(0.0, r.y);
+    }
+}
+
 __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, const double* __restrict__ gamma,
                                                        const double2* __restrict__ Delta,
-                                                       const double2* __restrict__ Lambda, double2* __restrict__ Q,
-                                                       const double* __restrict__ eta, long long m)
+                                                       const double2* __restrict__ Lambda,
+                                                       const double2* __restrict__ Over, int compact,
+                                                       double2* __restrict__ Q, const double* __restrict__ eta, long long m)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const double g = gamma[i];
-    const double2 r = R[i], d = Delta[i], l = Lambda[i];
+    const double2 r = R[i];
+    double2 d, l;
+    read_trade(Delta, Lambda, Over, compact, i, d, l);
     const double2 rn = make_double2((r.x + g * d.x) - l.x, (r.y + g * d.y) - l.y);
     R[i] = rn;
     if (Q) {
@@ -1214,11 +1266,32 @@ __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, 
 }
 
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  double2* Q, const double* eta, int64_t m, hipStream_t s)
+                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, hipStream_t s)
 {
     if (m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, Q,
-                       eta, (long long)m);
+    hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, Over,
+                       compact, Q, eta, (long long)m);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void expand_trades(const double2* __restrict__ rec, const double2* __restrict__ ovA,
+                                                     const double2* __restrict__ ovB, double2* __restrict__ Delta,
+                                                     double2* __restrict__ Lambda, long long m)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    double2 d, l;
+    read_trade(rec, ovA, ovB, 1, i, d, l);
+    Delta[i] = d;
+    Lambda[i] = l;
+}
+
+hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const double2* ovB, double2* Delta, double2* Lambda,
+                                int64_t m, hipStream_t s)
+{
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_trades, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, rec, ovA, ovB, Delta, Lambda,
+                       (long long)m);
     return hipGetLastError();
 }
 

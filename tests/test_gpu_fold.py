@@ -286,3 +286,47 @@ def test_packed_fee_token_records(n_fees):
     Do, Lo, psi_o, acc_o = oracle_sweep([bp, bg], n, v, nthreads=8)
     assert rel_to_max(res[1][0], psi_o) <= 1e-12
     np.testing.assert_array_equal(res[1][2][:len(bp)], Do[:len(bp)])
+
+
+def test_compact_trade_records_are_lossless():
+    """Option "compact_trades" (default 1): a materialising sweep writes ONE 16-byte record per pool ({+Δ₁, Λ₂} or
+    {−Δ₂, Λ₁}; both-direction pools -- γ > 1 -- go through overflow rows).  cfmm_get_trades, cfmm_get_trades_range,
+    cfmm_trades_dev and update_reserves! must see exactly the trades of the plain 32-byte layout."""
+    import ctypes
+    n = 48
+    bp, bg = synth.product_pools(60_000, n, seed=121), synth.geomean_pools(40_000, n, seed=122)
+    bg.γ[::7] = 1.02                      # fees above 1: both directions of such a pool can trade
+    bp.γ[::11] = 1.0
+    bu = synth.univ3_pools(8_000, n, 6, seed=123)
+    v = synth.sweep_prices(n, seed=124, spread=0.02)   # near the no-arbitrage manifold: many idle pools, some γ > 1 pools in both directions
+    res = {}
+    for compact in (1, 0):
+        be = cr.DeviceBackend(n, [bp, bg, bu])
+        be.ctx.set_option("compact_trades", compact)
+        try:
+            psi, acc = be.find_arb(v)
+            D, L = be.trades()
+            Dw, Lw = be.ctx.trades_range(1, 5, 30_000)
+            da, la = be.ctx.trades_dev()
+            m = len(D)
+            hD, hL = np.empty((m, 2)), np.empty((m, 2))
+            import torch
+            torch.cuda.synchronize()
+            hip = ctypes.CDLL("libamdhip64.so")
+            assert hip.hipDeviceSynchronize() == 0
+            assert hip.hipMemcpy(hD.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(da), m * 16, 2) == 0
+            assert hip.hipMemcpy(hL.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(la), m * 16, 2) == 0
+            be.ctx.update_reserves()
+            res[compact] = (psi, acc, D, L, Dw, Lw, hD, hL, be.ctx.reserves(0, len(bp)), be.ctx.reserves(1, len(bg)))
+        finally:
+            be.close()
+    both = np.count_nonzero((res[0][2] > 0).all(axis=1) | ((res[0][2][:, 0] > 0) & (res[0][3][:, 0] > 0)))
+    assert both > 0, "the market must contain pools that trade in both directions (overflow rows)"
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[1][6], res[1][2])      # expanded device arrays == downloaded trades
+    np.testing.assert_array_equal(res[1][7], res[1][3])
+    np.testing.assert_array_equal(res[1][4], res[1][2][60_005:90_005])
+    Do, Lo, psi_o, _ = oracle_sweep([bp, bg, bu], n, v, nthreads=8)
+    np.testing.assert_array_equal(res[1][2][:60_000], Do[:60_000])
+    np.testing.assert_array_equal(res[1][2][100_000:], Do[100_000:])
