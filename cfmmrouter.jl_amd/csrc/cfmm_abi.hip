@@ -1689,7 +1689,7 @@ int cfmm_trades_dev(cfmm_ctx* c, const double** d_delta, const double** d_lambda
     CFMM_SINGLE_ONLY(c, "cfmm_trades_dev");
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
-    if (c->opt_compact_trades != 0 && !global_bins(c)) {
+    if (c->have_trades ? c->trades_compact != 0 : (c->opt_compact_trades != 0 && !global_bins(c))) {
         // device consumers get the reference's layout: the compact records of the latest materialising sweep are
         // expanded (asynchronously, on the context's stream) into {Δ₁, Δ₂} / {Λ₁, Λ₂} arrays -- call again after
         // every sweep whose trades are wanted

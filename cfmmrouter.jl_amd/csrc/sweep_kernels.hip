@@ -610,11 +610,11 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     if constexpr (U == 1) {
         // One pool per lane per tile.  The first tile's pool state is requested before v and the
         // bins are staged in LDS, so that HBM round trip is not exposed behind the barrier.
-        // (Requesting tile k+1 before solving tile k was measured twice: round 1, -10 %; round 2 with an
+        // (Requesting tile k+1 before solving tile k was measured three times: round 1, -10 %; round 2 with an
         // UNCONDITIONAL next-tile load -- a conditional one makes the compiler wait for it at the join,
-        // before the arithmetic -- and the overlap verified in the ISA: +-0 on every workload, with or
-        // without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt).  Not kept: it
-        // only costs registers.)
+        // before the arithmetic -- and the overlap verified in the ISA: +-0 cache-warm on every workload, with
+        // or without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt), and again +-0 with
+        // the pool state coming from HBM (config5: 7 % slower).  Not kept: it only costs registers.)
         // Tile order alternates between consecutive sweeps (a.reverse): block-strided "phases" are walked
         // first-to-last by one sweep and last-to-first by the next, so each sweep begins on the pool data the
         // previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a

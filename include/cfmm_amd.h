@@ -99,7 +99,10 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's L2 -- two sweeps
  * at the same v then agree to summation-order rounding (trades: bit for bit), every second one bit for bit; 0: always
  * forwards, every sweep bit-identical), "pack" (default 1: sweeps read an 8-byte {token pair, fee-table index} record
- * instead of gamma + Ai when a launch's distinct fees fit a 256-entry table; same results).  Unknown keys are
+ * instead of gamma + Ai when a launch's distinct fees fit a 256-entry table; same results), "compact_trades" (default 1:
+ * a materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2, Lambda1}, a two-coin trade has
+ * one direction -- plus overflow rows for pools whose four values do not fit that form; cfmm_get_trades* decode it and
+ * cfmm_trades_dev expands it, bit for bit the rows of the 0 setting = separate Delta / Lambda rows).  Unknown keys are
  * CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
  * is set to 1 when the library is loaded unless already set (kernel arguments in device memory: -10 % per step);
  * CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */
@@ -182,7 +185,9 @@ int cfmm_dual_value(cfmm_ctx* ctx, double* acc);
  * buffer a sharded run all-reduces (one collective per evaluation).  Asynchronous on the
  * context's stream.  materialize != 0: also write Delta/Lambda (find_arb! semantics). */
 int cfmm_sweep_dev(cfmm_ctx* ctx, const double* d_v, double* d_out, int materialize);
-/* Device addresses of the trade buffers ([m_total][2] doubles each), valid until pools change. */
+/* Device addresses of the trade rows of the latest materialising sweep ([m_total][2] doubles each, the
+ * reference's Delta / Lambda layout), valid until pools change.  With "compact_trades" (default) these
+ * are expanded copies written on the context's stream by this call: call it again after a later sweep. */
 int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lambda);
 
 /* With option "time_kernels"=1 every sweep launch is bracketed by hipEvents on the launch
