@@ -145,6 +145,18 @@ def route_leg(name, batches, n):
         if solver == "native":   # where the one-call route! spends its time: device sweeps vs the host L-BFGS-B
             out["native_sweep_ms"] = 1e3 * r.info["sweep_seconds"]
             out["native_host_solver_ms"] = 1e3 * (r.info["total_seconds"] - r.info["sweep_seconds"])
+            # the same call with launch-when-ready evaluations instead of pre-armed ones (option "armed" = 0)
+            if isinstance(r._backend, cr.DeviceBackend) and r._backend.ctx.get_option("armed"):
+                r._backend.ctx.set_option("armed", 0)
+                cr.route_(r, v=v0, solver=solver)
+                t_un = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    cr.route_(r, v=v0, solver=solver)
+                    t_un.append(time.perf_counter() - t0)
+                out["native_unarmed_ms"] = 1e3 * min(t_un)
+                r._backend.ctx.set_option("armed", 1)
+                cr.route_(r, v=v0, solver=solver)
         out["_psi" if solver == "scipy" else "_psi_native"] = cr.netflows(r).copy()
     r.close()
     return out

@@ -155,6 +155,12 @@ struct cfmm_ctx {
     double* d_gtab = nullptr;     // [groups][kMaxFeeTable] fee tables of the launches (packed pool records)
     size_t gtab_cap = 0;
     unsigned* d_sync = nullptr;   // [kSyncWords] arrival counters of the in-launch fold (zero between launches)
+    // pre-armed evaluations of cfmm_route (sweep.h SweepArgs::arm_word): [n_pad] v, then the word, in FINE-GRAINED
+    // device memory that the host writes through the PCIe BAR (null: no large BAR, or the self-check failed)
+    double* d_arm = nullptr;
+    uint64_t arm_seq = 0;         // sequence number of the latest armed launch
+    bool arm_pending = false;     // an armed launch is enqueued and has not been signalled or cancelled yet
+    uint64_t arm_flag = 0;        // completion-flag value that launch will raise
     uint64_t flag_seq = 0;        // host-visible completion flag: value the NEXT flagged sweep will raise
     bool last_inline = false;     // the latest enqueue_sweep folded inside the sweep launch
     bool last_flagged = false;    // ... and raises the host flag (the caller may poll it instead of the stream)
@@ -190,6 +196,9 @@ struct cfmm_ctx {
     uint64_t sweep_count = 0;
     int64_t opt_inline_fold = 0;   // 1: partial rows are folded inside the sweep launch (single-launch evaluations, n <= kMaxFoldTokens);
                                    //    measured 1-3 us per step SLOWER than the separate fold launch, kept as an option
+    int64_t opt_armed = 1;         // 1: cfmm_route enqueues evaluation k+1 while evaluation k runs; its blocks wait on the device for
+                                   //    the host to write v through the PCIe BAR (hides the launch latency: -4..-5 us per evaluation)
+    int64_t opt_arm_timeout_ms = 2000; // bound of that wait
     int64_t opt_host_flag = 1;     // 1: zero-copy host-pointer sweeps end by raising a flag in mapped host memory that the
                                    //    caller polls, instead of waiting for the stream (saves the end-of-kernel + signal path)
 
@@ -604,7 +613,8 @@ hipEvent_t take_event(cfmm_ctx* c)
 }
 
 // Enqueue one full evaluation on c->stream: every segment's sweep, then the row fold.
-int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_flag = false)
+int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_flag = false,
+                  uint64_t arm_seq = 0)
 {
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
@@ -613,7 +623,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     // One launch per evaluation: the partial rows are folded by extra blocks of that launch.
     const bool sharded = !c->peers.empty();   // fold + all-reduce over the peer mappings in one launch
     const bool inline_fold = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
-                             c->n <= kMaxFoldTokens && c->d_sync != nullptr;
+                             c->n <= kMaxFoldTokens && c->d_sync != nullptr && arm_seq == 0;
+    const unsigned long long* arm_word = arm_seq ? reinterpret_cast<const unsigned long long*>(c->d_arm + c->n_pad) : nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
     const bool flagged = want_host_flag && !gb && (sharded || c->rows_total > 0) && c->d_sync != nullptr;
     c->last_inline = inline_fold;
@@ -645,6 +656,9 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.fold_out = d_out;
         a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
         a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
+        a.arm_word = arm_word;
+        a.arm_seq = arm_seq;
+        a.arm_timeout = (long long)c->opt_arm_timeout_ms * 100000ll;   // 100 MHz wall clock
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
@@ -736,7 +750,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         } else {
             e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, c->groups.back().block, ra, rb,
                               c->d_sync, flagged ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr,
-                              flagged ? ++c->flag_seq : 0);
+                              flagged ? ++c->flag_seq : 0, ArmWord{arm_word, arm_seq});
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
@@ -789,10 +803,30 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
     return CFMM_OK;
 }
 
+// {Ψ, acc} have arrived in the pinned staging buffer: take them over into last_out.
+int take_host_out(cfmm_ctx* c)
+{
+    const double* h_out = c->h_stage + c->n;
+    c->last_out.assign(h_out, h_out + c->n + 1);
+    for (int j = 0; j <= c->n; ++j)
+        if (!std::isfinite(c->last_out[(size_t)j])) {
+            c->have_out = false;
+            // a fold that gave up may have left its arrival / ticket words non-zero: clean them for the next sweep
+            (void)hipStreamSynchronize(c->stream);
+            if (c->d_sync) (void)hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned));
+            if (!c->peers.empty())
+                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
+                                               "publish) or a shard overflowed", j);
+            return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: pool arithmetic overflowed, or the in-launch fold "
+                                           "timed out", j);
+        }
+    c->have_out = true;
+    return CFMM_OK;
+}
+
 // Second half: wait for {Ψ, acc} to be on the host and take them over into last_out.
 int host_sweep_end(cfmm_ctx* c)
 {
-    double* h_out = c->h_stage + c->n;
     bool flag_seen = false;
     if (c->last_flagged) {
         // The last fold block wrote {Ψ, acc} through to this pinned buffer and then raised the flag
@@ -817,20 +851,89 @@ int host_sweep_end(cfmm_ctx* c)
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    c->last_out.assign(h_out, h_out + c->n + 1);
-    for (int j = 0; j <= c->n; ++j)
-        if (!std::isfinite(c->last_out[(size_t)j])) {
-            c->have_out = false;
-            // a fold that gave up may have left its arrival / ticket words non-zero: clean them for the next sweep
-            (void)hipStreamSynchronize(c->stream);
-            if (c->d_sync) (void)hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned));
-            if (!c->peers.empty())
-                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
-                                               "publish) or a shard overflowed", j);
-            return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: pool arithmetic overflowed, or the in-launch fold "
-                                           "timed out", j);
-        }
-    c->have_out = true;
+    return take_host_out(c);
+}
+
+// ---- pre-armed evaluations (cfmm_route; sweep.h SweepArgs::arm_word) ---------------------------
+// cfmm_route's evaluations are strictly sequential (the solver needs {Ψ, acc} of v_k to choose v_k+1), so the ~5 us
+// between "v is ready" and "the kernel's first wavefront runs" (launch call, doorbell, command processor, dispatch)
+// sit on the critical path of every evaluation.  Armed operation takes them off it: evaluation k+1 -- sweep and
+// fold -- is enqueued right after evaluation k has been signalled, becomes resident when k's fold retires, issues its
+// first pool loads, clears its LDS bins and then polls a word in device memory; the host writes v_k+1 and the word
+// straight into (fine-grained) device memory through the PCIe BAR.  Measured on the handoff alone
+// (scripts/native/handoff.hip, profiles/r02_handoff.txt): 11.2 us launch-when-ready vs 6.3 us armed.
+// The one launch left over when the solver stops is cancelled through the same word.
+bool can_arm(cfmm_ctx* c)
+{
+    if (c->opt_armed == 0 || !c->d_arm || !c->shards.empty() || !c->peers.empty() || c->opt_zero_copy == 0 || !c->d_stage ||
+        c->opt_host_flag == 0 || c->opt_time_kernels != 0 || c->opt_wave_split != 0 || c->n > 1024 || !c->d_sync ||
+        c->stream != c->own_stream || global_bins(c))
+        return false;
+    return ensure_geometry(c) == CFMM_OK && c->rows_total > 0;
+}
+
+void armed_write(cfmm_ctx* c, const double* v, uint64_t word)
+{
+    if (v) std::memcpy(c->d_arm, v, (size_t)c->n * sizeof(double));   // write-combining stores through the BAR
+    __builtin_ia32_sfence();                                            // v before the word (WC buffers flush out of order)
+    *reinterpret_cast<volatile unsigned long long*>(c->d_arm + c->n_pad) = word;
+    __builtin_ia32_sfence();                                            // and out now
+}
+
+int armed_enqueue(cfmm_ctx* c)
+{
+    const uint64_t seq = ++c->arm_seq;
+    int rc = enqueue_sweep(c, c->d_arm, c->d_stage + c->n, false, true, seq);
+    if (rc != CFMM_OK) return rc;
+    c->arm_flag = c->flag_seq;
+    c->arm_pending = true;
+    return CFMM_OK;
+}
+
+void armed_cancel(cfmm_ctx* c)
+{
+    if (!c->arm_pending) return;
+    armed_write(c, nullptr, c->arm_seq | kArmCancel);
+    c->arm_pending = false;
+    --c->sweep_count;   // the cancelled launch swept nothing: later sweeps keep the tile directions of an unarmed run
+}
+
+// One fused evaluation at v through the armed launch (enqueuing it first if none is waiting), with the next one
+// enqueued behind it while it runs.
+int armed_eval(cfmm_ctx* c, const double* v)
+{
+    int rc = check_prices(c, v);
+    if (rc != CFMM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->arm_pending) {
+        rc = armed_enqueue(c);
+        if (rc != CFMM_OK) return rc;
+    }
+    const uint64_t want = c->arm_flag;
+    armed_write(c, v, c->arm_seq);
+    c->arm_pending = false;
+    const int rc_next = armed_enqueue(c);   // evaluation k+1 goes out while k runs
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_stage + 2 * c->n + 1);
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        if (*flag == want) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((spins & 0xffff) == 0xffff &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3 * (double)c->opt_arm_timeout_ms + 1.0)
+            break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) {
+        armed_cancel(c);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_sync) (void)hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned));
+        c->have_out = false;
+        return fail(c, CFMM_ERR_STATE, "armed evaluation did not complete (the device never saw its price vector)");
+    }
+    rc = take_host_out(c);
+    if (rc != CFMM_OK) { armed_cancel(c); return rc; }
+    if (rc_next != CFMM_OK) return rc_next;
     return CFMM_OK;
 }
 
@@ -1191,6 +1294,32 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
         (void)hipGetLastError();
         c->d_stage = nullptr; // fall back to explicit copies
     }
+    {   // armed evaluations: fine-grained device memory the host can write through the PCIe BAR (optional)
+        int large_bar = 0;
+        const char* env = std::getenv("CFMM_AMD_ARMED");
+        if (!(env && env[0] == '0') &&
+            hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar != 0) {
+            const size_t words = (size_t)c->n_pad + 8;
+            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->d_arm), words * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess) {
+                // self-check: what the host stores must be what the device holds
+                std::vector<double> probe(words), back(words, 0.0);
+                for (size_t j = 0; j < words; ++j) probe[j] = 1.0 + (double)j;
+                std::memcpy(c->d_arm, probe.data(), words * sizeof(double));
+                __builtin_ia32_sfence();
+                if (hipMemcpy(back.data(), c->d_arm, words * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess || back != probe) {
+                    (void)hipGetLastError();
+                    (void)hipFree(c->d_arm);
+                    c->d_arm = nullptr;
+                } else {
+                    std::memset(c->d_arm, 0, words * sizeof(double));
+                    __builtin_ia32_sfence();
+                }
+            } else {
+                (void)hipGetLastError();
+                c->d_arm = nullptr;
+            }
+        }
+    }
     // the dynamic-LDS ceiling is a per-function, process-wide attribute: always raise it to the
     // full 160 KiB so that contexts with different n_tokens cannot shrink each other's limit
     HIP_TRY_C(prepare_kernels(160 * 1024));
@@ -1256,6 +1385,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     (void)hipFree(c->d_flow); (void)hipFree(c->d_entries); (void)hipFree(c->d_chunks);
     (void)hipFree(c->d_tok_chunk_off); (void)hipFree(c->d_chunk_sums);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->d_arm) (void)hipFree(c->d_arm);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1298,6 +1428,8 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "alternate")) return &c->opt_alternate;
     if (!std::strcmp(key, "pack")) return &c->opt_pack;
     if (!std::strcmp(key, "compact_trades")) return &c->opt_compact_trades;
+    if (!std::strcmp(key, "armed")) return &c->opt_armed;
+    if (!std::strcmp(key, "arm_timeout_ms")) return &c->opt_arm_timeout_ms;
     if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
     if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;
     if (!std::strcmp(key, "cost_univ3")) return &c->opt_cost_univ3;
@@ -1886,9 +2018,15 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     int sweeps = 0, rc_inner = CFMM_OK;
     double sweep_s = 0.0;
     const auto t_begin = std::chrono::steady_clock::now();
+    const bool armed = can_arm(c);
+    struct ArmGuard {   // whatever path leaves this function: no launch stays behind waiting for a price vector
+        cfmm_ctx* c;
+        ~ArmGuard() { armed_cancel(c); }
+    } arm_guard{c};
     auto timed_sweep = [&](const double* x, bool mat) {
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = host_sweep(c, x, mat);
+        if (mat) armed_cancel(c);
+        const int rc = (armed && !mat) ? armed_eval(c, x) : host_sweep(c, x, mat);
         sweep_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ++sweeps;
         return rc;

@@ -99,7 +99,17 @@ struct SweepArgs {
     double* fold_out;            // [n+1] {Ψ, acc}
     unsigned long long* host_flag; // optional (mapped pinned host memory): set to host_seq by the last fold block
     unsigned long long host_seq;   // once every fold block's part of fold_out has been written through to it
+    // Pre-armed launch (arm_word != null; cfmm_route): the kernel is enqueued BEFORE its price vector exists and every
+    // block, after issuing its first pool loads and clearing its bins, waits until the host has written v into `v`
+    // (fine-grained device memory, through the PCIe BAR) and then arm_seq into *arm_word -- the launch latency is
+    // spent while the previous evaluation and the host solver run.  *arm_word == arm_seq | kArmCancel: the launch
+    // is not needed (the blocks skip their pools, the fold returns without output).  Waits are bounded by
+    // arm_timeout ticks of the 100 MHz wall clock; a block that gives up poisons the dual column with NaN.
+    const unsigned long long* arm_word;
+    unsigned long long arm_seq;
+    long long arm_timeout;
 };
+constexpr unsigned long long kArmCancel = 1ull << 63;
 constexpr int kArriveShards = 16;    // arrival counters (one 128-B line each): block b arrives on shard b % 16
 constexpr int kSyncStride = 32;      // uint32 words per shard line
 constexpr int kSyncWords = (kArriveShards + 1) * kSyncStride;   // + the fold blocks' own "done" ticket line
@@ -164,9 +174,14 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
 // `block` = the block size of the sweep launches that produced the rows (same summation order as the in-launch fold).
 // host_flag != null (needs sync): out is mapped host memory; the last fold block sets *host_flag = host_seq after
 // every block's part of out has been written through.
+struct ArmWord {                 // see SweepArgs::arm_word; {nullptr, 0} = not armed
+    const unsigned long long* word;
+    unsigned long long seq;
+};
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, unsigned* sync = nullptr,
-                         unsigned long long* host_flag = nullptr, unsigned long long host_seq = 0);
+                         unsigned long long* host_flag = nullptr, unsigned long long host_seq = 0,
+                         ArmWord arm = ArmWord{nullptr, 0});
 
 // Sharded runs (cfmm_set_peers): the row fold fused with the one-shot all-reduce over xGMI peer
 // mappings (reduce_gather in sweep_kernels.hip): block b folds its kReduceCols columns, publishes

@@ -515,23 +515,46 @@ __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
     return L;
 }
 
-// v -> LDS, bins <- 0, barrier.  Whole block.
+// Pre-armed launch: one lane waits for the host's word (see SweepArgs::arm_word).  true = v is in place.
+__device__ __forceinline__ bool wait_armed(const SweepArgs& a)
+{
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(a.arm_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (w == a.arm_seq) return true;
+        if (w == (a.arm_seq | kArmCancel)) return false;
+        if ((long long)wall_clock64() - t0 > a.arm_timeout) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// bins <- 0, fee table and v -> LDS, barrier.  Whole block.  Returns false only for a pre-armed launch that was
+// cancelled or gave up waiting for its prices (block-uniform).
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ void stage_prices(const SweepArgs& a, const SweepLds& L)
+__device__ __forceinline__ bool stage_prices(const SweepArgs& a, const SweepLds& L)
 {
     const int tid = threadIdx.x;
     const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
     const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
     const bool logs = !GBINS && a.need_logv;
-    for (int j = tid; j < n_stage; j += BLOCK) {
-        const double vj = a.v[j];
-        L.v_lds[j] = vj;
-        if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
-    }
     for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
     if (!GBINS)
         for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
+    bool live = true;
+    const bool armed = !GBINS && a.arm_word != nullptr;   // kernel argument: block-uniform
+    if (armed) {
+        if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
+        __syncthreads();
+        live = L.wsum[0] != 0.0;
+    }
+    for (int j = tid; j < n_stage; j += BLOCK) {
+        // armed: the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
+        const double vj = armed ? __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.v[j];
+        L.v_lds[j] = vj;
+        if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
+    }
     __syncthreads();
+    return live;
 }
 
 // The tile loop of one pool family over a SHARE of a segment: lane `sub_tid` of a group of
@@ -628,7 +651,12 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         typename Ops::Raw cur = {};
         bool ok = left > 0;
         if (ok) cur = ops.load(i);
-        if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
+        if constexpr (STAGE) {
+            if (!stage_prices<BLOCK, GBINS>(a, L)) {       // a pre-armed launch that is not needed (or gave up)
+                ok = false;
+                acc = __builtin_nan("");                   // poisons the dual column should anyone fold this row
+            }
+        }
         if constexpr (Ops::kWaveCooperative) {
             while (__any(ok)) {                          // the wavefront stays together
                 process(cur, i, ok);
@@ -647,10 +675,12 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
             }
         }
     } else {
-        if constexpr (STAGE) stage_prices<BLOCK, GBINS>(a, L);
+        bool live = true;
+        if constexpr (STAGE) live = stage_prices<BLOCK, GBINS>(a, L);
+        if (!live) acc = __builtin_nan("");
         const int64_t tile_pools = (int64_t)sub_block * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-        const int64_t mine = bid < n_tiles ? (n_tiles - bid + nblocks - 1) / nblocks : 0;
+        const int64_t mine = live && bid < n_tiles ? (n_tiles - bid + nblocks - 1) / nblocks : 0;
         for (int64_t k = 0; k < mine; ++k) {   // uniform trip count within the group
             const int64_t tile = bid + (a.reverse ? mine - 1 - k : k) * nblocks;
             const int64_t base = tile * tile_pools + sub_tid;
@@ -881,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         a.Over = sg.Over;
         a.gflow = sg.gflow;
         const SweepLds L = carve_lds<BLOCK, GBINS>(a);
-        stage_prices<BLOCK, GBINS>(a, L);
+        (void)stage_prices<BLOCK, GBINS>(a, L);           // never armed (host side: wave_split excludes arming)
         double acc = 0.0;
         switch (sg.kind) {                                // wavefront-uniform
         case 0:
@@ -952,9 +982,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int rows, int n1,
                                                          double* __restrict__ out, unsigned* sync,
-                                                         unsigned long long* host_flag, unsigned long long host_seq)
+                                                         unsigned long long* host_flag, unsigned long long host_seq,
+                                                         ArmWord arm)
 {
     __shared__ double red[(BLOCK / 64) * kReduceCols];
+    // the fold of a pre-armed evaluation that was cancelled (or never got its prices) has nothing to publish; the
+    // word cannot change between the threads' loads: the host moves on only after this launch's completion flag
+    if (arm.word && __hip_atomic_load(arm.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != arm.seq) return;
     const double tsum = fold_columns<BLOCK, false>(partials, rows, n1, blockIdx.x, red);
     fold_finish(tsum, true, n1, out, sync, (int)gridDim.x, false, host_flag, host_seq);
 }
@@ -1206,16 +1240,16 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
 
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
                          hipEvent_t e0, hipEvent_t e1, unsigned* sync, unsigned long long* host_flag,
-                         unsigned long long host_seq)
+                         unsigned long long host_seq, ArmWord arm)
 {
     dim3 g((n1 + kReduceCols - 1) / kReduceCols);
     if (!sync) host_flag = nullptr;
     if (block == kBigBlock)
-        launch_k(&reduce_partials<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+        launch_k(&reduce_partials<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
     else if (block == kMidBlock)
-        launch_k(&reduce_partials<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+        launch_k(&reduce_partials<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
     else
-        launch_k(&reduce_partials<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq);
+        launch_k(&reduce_partials<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
     return hipGetLastError();
 }
 

@@ -102,7 +102,12 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * instead of gamma + Ai when a launch's distinct fees fit a 256-entry table; same results), "compact_trades" (default 1:
  * a materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2, Lambda1}, a two-coin trade has
  * one direction -- plus overflow rows for pools whose four values do not fit that form; cfmm_get_trades* decode it and
- * cfmm_trades_dev expands it, bit for bit the rows of the 0 setting = separate Delta / Lambda rows).  Unknown keys are
+ * cfmm_trades_dev expands it, bit for bit the rows of the 0 setting = separate Delta / Lambda rows), "armed" (default 1:
+ * cfmm_route enqueues evaluation k+1 while evaluation k runs; its blocks wait on the device -- bounded by
+ * "arm_timeout_ms", default 2000 -- until the host has written the next price vector straight into device memory
+ * through the PCIe BAR, which takes the launch latency off the critical path of every evaluation; needs a large-BAR
+ * system, otherwise -- or with CFMM_AMD_ARMED=0 in the environment -- the evaluations are launched when their prices
+ * are ready; identical results either way).  Unknown keys are
  * CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
  * is set to 1 when the library is loaded unless already set (kernel arguments in device memory: -10 % per step);
  * CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */

@@ -1,0 +1,207 @@
+// handoff.hip -- how fast can the host hand a price vector to a kernel that is ALREADY resident?
+// (pre-armed sweeps.)  One "evaluation" here = 256 blocks each read n doubles of v and
+// arrive at a counter; the last one raises a completion flag in mapped host memory.  Timed on the
+// host from "v is ready" to "flag observed":
+//   (L) launch the kernel when v is ready (v read from mapped host memory)     = what cfmm_eval does today
+//   (A) kernel launched earlier; every block polls a word in mapped HOST memory
+//   (B) kernel launched earlier; block 0 polls mapped host memory, copies v to device memory and
+//       releases a device word the other blocks poll
+//   (C) kernel launched earlier; the host writes v and the word straight into DEVICE memory
+//       (fine-grained allocation through the PCIe BAR), all blocks poll that
+//   (D) as (L), but the host has written v into device memory through the BAR before the launch
+// Every wait is bounded by wall-clock time (1 s), so a lost signal cannot hang the GPU.
+// build: hipcc --offload-arch=gfx950 -O3 -o scripts/native/handoff.bin scripts/native/handoff.hip
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <csetjmp>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static sigjmp_buf g_jmp;
+constexpr long long kTimeoutTicks = 100000000ll;   // 1 s of the 100 MHz wall clock
+
+__device__ __forceinline__ bool wait_word(const unsigned long long* w, unsigned long long want, bool system)
+{
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        const unsigned long long x = system ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                            : __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x == want) return true;
+        if ((long long)wall_clock64() - t0 > kTimeoutTicks) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// mode 0: no wait (launch-when-ready)   1: all poll `sig` (system scope)   2: leader relays through `relay`
+// mode 3: all poll `sig` at agent scope... the host wrote it through the BAR, so use system-scope loads too
+__global__ __launch_bounds__(256) void eval_k(int mode, const unsigned long long* sig, unsigned long long seq,
+                                              const double* v_src, double* v_dev, unsigned long long* relay, int n,
+                                              unsigned* ticket, double* sink, unsigned long long* done)
+{
+    __shared__ double vs[1024];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    bool ok = true;
+    const double* v = v_src;
+    if (mode == 1 || mode == 3) {
+        if (tid == 0) ok_s = wait_word(sig, seq, true) ? 1 : 0;
+        __syncthreads();
+        ok = ok_s != 0;
+    } else if (mode == 2) {
+        if (blockIdx.x == 0) {
+            if (tid == 0) ok_s = wait_word(sig, seq, true) ? 1 : 0;
+            __syncthreads();
+            ok = ok_s != 0;
+            for (int j = tid; j < n; j += 256)
+                __hip_atomic_store(v_dev + j, __hip_atomic_load(v_src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(relay, ok ? seq : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (tid == 0) ok_s = wait_word(relay, seq, false) ? 1 : 0;
+            __syncthreads();
+            ok = ok_s != 0;
+        }
+        v = v_dev;
+    }
+    double s = 0.0;
+    if (ok) {
+        for (int j = tid; j < n; j += 256)
+            vs[j] = (mode == 2)   ? __hip_atomic_load(v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    : (mode == 0 || mode == 4) ? v[j]      // a fresh launch: plain loads, as the library's stage_prices does
+                                  : __hip_atomic_load(v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) s += vs[j];
+    }
+    if (s == 12345.678) sink[blockIdx.x] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, ok ? seq : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+static double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void busy_us(double us)
+{
+    const double t0 = now_us();
+    while (now_us() - t0 < us) {}
+}
+
+int main()
+{
+    CK(hipSetDevice(0));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int n = 256, grid = 256;
+
+    // mapped host memory: v, signal word, completion word
+    double* h_v; unsigned long long *h_sig, *h_done;
+    CK(hipHostMalloc((void**)&h_v, 8192, hipHostMallocMapped));
+    CK(hipHostMalloc((void**)&h_sig, 64, hipHostMallocMapped));
+    CK(hipHostMalloc((void**)&h_done, 64, hipHostMallocMapped));
+    double* d_hv; unsigned long long *d_hsig, *d_hdone;
+    CK(hipHostGetDevicePointer((void**)&d_hv, h_v, 0));
+    CK(hipHostGetDevicePointer((void**)&d_hsig, h_sig, 0));
+    CK(hipHostGetDevicePointer((void**)&d_hdone, h_done, 0));
+    for (int j = 0; j < 1024; ++j) h_v[j] = 1.0 + j;
+    *h_sig = 0; *h_done = 0;
+
+    double *d_v, *d_sink; unsigned long long* d_relay; unsigned* d_ticket;
+    CK(hipMalloc((void**)&d_v, 8192));
+    CK(hipMalloc((void**)&d_sink, grid * 8));
+    CK(hipMalloc((void**)&d_relay, 64));
+    CK(hipMalloc((void**)&d_ticket, 64));
+    CK(hipMemset(d_relay, 0, 64));
+    CK(hipMemset(d_ticket, 0, 64));
+
+    // device memory the host can write: fine-grained allocation; probe the write in a child process
+    char* d_fine = nullptr;
+    bool bar_ok = false;
+    if (hipExtMallocWithFlags((void**)&d_fine, 16384, hipDeviceMallocFinegrained) == hipSuccess) {
+        CK(hipMemset(d_fine, 0, 16384));
+        CK(hipDeviceSynchronize());
+        struct sigaction sa, old_segv, old_bus;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = [](int) { siglongjmp(g_jmp, 1); };
+        sigaction(SIGSEGV, &sa, &old_segv);
+        sigaction(SIGBUS, &sa, &old_bus);
+        int status = 0;
+        if (sigsetjmp(g_jmp, 1) == 0) {
+            volatile unsigned long long* p = (volatile unsigned long long*)d_fine;
+            p[0] = 42;
+            bar_ok = p[0] == 42;
+        } else {
+            status = 1;
+        }
+        sigaction(SIGSEGV, &old_segv, nullptr);
+        sigaction(SIGBUS, &old_bus, nullptr);
+        printf("fine-grained device memory writable from the host: %s (fault %d)\n", bar_ok ? "yes" : "no", status);
+    } else {
+        printf("hipExtMallocWithFlags(finegrained) failed\n");
+    }
+
+    auto run = [&](int mode, const char* name) {
+        const unsigned long long* sig = d_hsig;
+        const double* vsrc = d_hv;
+        volatile unsigned long long* host_sig = h_sig;
+        double* host_v = h_v;
+        if (mode == 3 || mode == 4) {
+            sig = (const unsigned long long*)(d_fine + 8192);
+            vsrc = (const double*)d_fine;
+            host_sig = (volatile unsigned long long*)(d_fine + 8192);
+            host_v = (double*)d_fine;
+        }
+        std::vector<double> t;
+        unsigned long long seq = 1000ull * (mode + 1);
+        for (int it = 0; it < 300; ++it) {
+            ++seq;
+            if (mode != 0 && mode != 4) {   // arm: launch now, signal later
+                hipLaunchKernelGGL(eval_k, dim3(grid), dim3(256), 0, st, mode, sig, seq, vsrc, d_v, d_relay, n, d_ticket, d_sink, d_hdone);
+                busy_us(25.0);     // the kernel is resident and polling by now (previous evaluation + host solver time)
+            }
+            const double t0 = now_us();
+            for (int j = 0; j < n; ++j) host_v[j] = 1.0 + j + it;   // "the solver's new v"
+            if (mode == 0 || mode == 4) {
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                hipLaunchKernelGGL(eval_k, dim3(grid), dim3(256), 0, st, mode, sig, seq, vsrc, d_v, d_relay, n, d_ticket, d_sink, d_hdone);
+            } else {
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                *host_sig = seq;
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            }
+            const double tl = now_us();
+            bool lost = false;
+            while (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != seq) {
+                if (now_us() - tl > 2e6) { lost = true; break; }
+            }
+            const double t1 = now_us();
+            CK(hipStreamSynchronize(st));
+            if (lost) { printf("%s: signal lost (done = %llx)\n", name, *h_done); return; }
+            if (it >= 50) t.push_back(t1 - t0);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-64s median %6.2f us   p10 %6.2f   p90 %6.2f\n", name, t[t.size() / 2], t[t.size() / 10], t[t.size() * 9 / 10]);
+    };
+    run(0, "(L) launch when v is ready, v from mapped host memory");
+    run(1, "(A) armed, all 256 blocks poll mapped host memory");
+    run(2, "(B) armed, block 0 polls host memory and relays v + word on the device");
+    if (bar_ok) run(3, "(C) armed, host writes v + word into device memory (BAR)");
+    if (bar_ok) run(4, "(D) launch when v is ready, v written into device memory (BAR)");
+    run(0, "(L) again");
+    return 0;
+}

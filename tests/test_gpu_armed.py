@@ -1,0 +1,96 @@
+"""Pre-armed evaluations of cfmm_route (sweep.h SweepArgs::arm_word): evaluation k+1 is enqueued while k runs and
+waits on the device for its price vector, which the host writes through the PCIe BAR.  Same launches, same
+arithmetic, same tile directions as the unarmed loop -- so results must be identical bit for bit."""
+import numpy as np
+import pytest
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from cfmmrouter_amd._lib import OBJ_BASKET_LIQUIDATION, OBJ_LINEAR_NONNEGATIVE
+
+pytestmark = pytest.mark.gpu
+
+
+def markets():
+    n = 64
+    yield "product", n, [synth.product_pools(150_000, n, seed=11)]
+    yield "mixed", n, [synth.product_pools(60_000, n, seed=3), synth.geomean_pools(40_000, n, seed=4),
+                       synth.bounded_product_pools(30_000, n, seed=5)]
+    n = 512
+    yield "wide", n, [synth.product_pools(200_000, n, seed=7)]
+
+
+def run_route(batches, n, kind, vec, idx, armed, v0=None, **opts):
+    be = cr.DeviceBackend(n, batches)
+    try:
+        be.ctx.set_option("armed", armed)
+        for k, val in opts.items():
+            be.ctx.set_option(k, val)
+        v, psi, info = be.ctx.route(kind, vec, idx, v0=v0)
+        D, L = be.trades()
+        psi2, acc2 = be.find_arb(v)                   # the context is in a clean state after the cancelled launch
+        D2, L2 = be.trades()
+        return v, psi, info, D, L, psi2, D2, L2
+    finally:
+        be.close()
+
+
+@pytest.mark.parametrize("name,n,batches", list(markets()), ids=lambda x: x if isinstance(x, str) else None)
+def test_armed_route_is_bit_identical_to_the_unarmed_loop(name, n, batches):
+    c = synth.linear_prices(n, seed=3)
+    a = run_route(batches, n, OBJ_LINEAR_NONNEGATIVE, c, 0, 1, v0=np.ones(n))
+    b = run_route(batches, n, OBJ_LINEAR_NONNEGATIVE, c, 0, 0, v0=np.ones(n))
+    assert a[2]["evaluations"] == b[2]["evaluations"] >= 3 and a[2]["sweeps"] == b[2]["sweeps"]
+    np.testing.assert_array_equal(a[0], b[0])         # v*
+    np.testing.assert_array_equal(a[1], b[1])         # Ψ(v*)
+    np.testing.assert_array_equal(a[3], b[3])         # Δ
+    np.testing.assert_array_equal(a[4], b[4])         # Λ
+    np.testing.assert_array_equal(a[6], a[3])         # a later plain find_arb! at v* reproduces the trades
+    np.testing.assert_array_equal(a[7], a[4])
+    assert np.max(np.abs(a[5] - a[1])) <= 1e-13 * np.max(np.abs(a[1]))
+
+
+def test_armed_route_basket_liquidation_many_evaluations():
+    """interior optimum (config-5 market shape): > 50 evaluations, each through an armed launch"""
+    n = 32
+    batches = [synth.bounded_product_pools(60_000, n, seed=21, consistent=True)]
+    basket = synth.basket(n, seed=2)
+    a = run_route(batches, n, OBJ_BASKET_LIQUIDATION, basket, 0, 1)
+    b = run_route(batches, n, OBJ_BASKET_LIQUIDATION, basket, 0, 0)
+    assert a[2]["evaluations"] == b[2]["evaluations"] > 20
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[3], b[3])
+
+
+def test_armed_route_repeated_and_interleaved_with_other_calls():
+    n = 64
+    batches = [synth.product_pools(50_000, n, seed=5), synth.geomean_pools(30_000, n, seed=6)]
+    c = synth.linear_prices(n, seed=9)
+    be = cr.DeviceBackend(n, batches)
+    try:
+        first = None
+        for rep in range(4):
+            v, psi, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=np.ones(n))
+            psi_e, acc_e = be.eval(v)                      # ordinary launches right behind a cancelled armed one
+            assert np.max(np.abs(psi_e - psi)) <= 1e-13 * np.max(np.abs(psi))
+            if first is None:
+                first = (v.copy(), info["evaluations"])
+            else:
+                np.testing.assert_array_equal(v, first[0])
+                assert info["evaluations"] == first[1]
+    finally:
+        be.close()
+
+
+def test_route_error_paths_leave_no_armed_launch_behind():
+    n = 16
+    be = cr.DeviceBackend(n, [synth.product_pools(5_000, n, seed=1)])
+    try:
+        with pytest.raises(Exception):
+            be.ctx.route(OBJ_LINEAR_NONNEGATIVE, np.ones(n), 0, v0=-np.ones(n))     # invalid prices: fails in the first evaluation
+        v, psi, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, np.ones(n), 0, v0=2 * np.ones(n), maxfun=2)  # solver stops early
+        psi2, acc = be.find_arb(v)
+        assert np.all(np.isfinite(psi2))
+    finally:
+        be.close()
