@@ -18,7 +18,8 @@ cd /tmp && export TMPDIR=/tmp
 for w in $PROF; do
   for mode in warm cold; do
     flag="--no-cold"; [ "$mode" = "cold" ] && flag="--cold-only"
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${w}_$mode -o $w -- python $R/bench.py --steps 100 --warmup 10 --no-cpu $flag --workload $w > $R/gpurun_out/prof_${w}_$mode.log 2>&1 < /dev/null
+    # CFMM_AMD_ARMED=0: route!'s pre-armed launches would count the time they wait for the host as kernel time
+    CFMM_AMD_ARMED=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${w}_$mode -o $w -- python $R/bench.py --steps 100 --warmup 10 --no-cpu $flag --workload $w > $R/gpurun_out/prof_${w}_$mode.log 2>&1 < /dev/null
     f=$(find $R/gpurun_out/prof_${w}_$mode -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && echo "== $w $mode" && head -4 "$f" | cut -c1-200
   done
