@@ -94,3 +94,26 @@ def test_route_error_paths_leave_no_armed_launch_behind():
         assert np.all(np.isfinite(psi2))
     finally:
         be.close()
+
+
+def test_armed_route_stress_never_stalls():
+    """300 routes back to back (> 4000 armed launches, 300 cancelled ones): a lost hand-over would show up as a
+    2 s stall (the device-side bound of the wait) or as an error."""
+    import time
+    n = 32
+    be = cr.DeviceBackend(n, [synth.product_pools(20_000, n, seed=8), synth.geomean_pools(8_000, n, seed=9)])
+    try:
+        c = synth.linear_prices(n, seed=4)
+        be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=np.ones(n))
+        worst, evals = 0.0, 0
+        for rep in range(300):
+            v0 = np.ones(n) * (1.0 + 0.001 * (rep % 7))
+            t0 = time.perf_counter()
+            v, psi, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=v0)
+            worst = max(worst, time.perf_counter() - t0)
+            evals += info["evaluations"]
+            assert np.all(np.isfinite(psi))
+        assert evals > 2000
+        assert worst < 0.5, f"slowest route took {worst:.3f} s"
+    finally:
+        be.close()
