@@ -658,7 +658,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
         a.arm_word = arm_word;
         a.arm_seq = arm_seq;
-        a.arm_timeout = (long long)c->opt_arm_timeout_ms * 100000ll;   // 100 MHz wall clock
+        a.arm_timeout = std::min<long long>(std::max<long long>(c->opt_arm_timeout_ms, 1), 10000) * 100000ll;   // ms -> ticks of the 100 MHz wall clock, at most 10 s
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
@@ -920,7 +920,8 @@ int armed_eval(cfmm_ctx* c, const double* v)
         if (*flag == want) { seen = true; break; }
         __builtin_ia32_pause();
         if ((spins & 0xffff) == 0xffff &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3 * (double)c->opt_arm_timeout_ms + 1.0)
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >
+                2e-3 * (double)std::min<int64_t>(std::max<int64_t>(c->opt_arm_timeout_ms, 1), 10000) + 1.0)
             break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
