@@ -257,6 +257,9 @@ def main():
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun even N=1 goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a healthy peer exchange takes microseconds and the bench's ranks run in lockstep: bound a broken one (the
+        # start-up check then falls back to RCCL on all ranks) by seconds, not by the library's 30 s default
+        os.environ.setdefault("CFMM_AMD_PEER_TIMEOUT_S", "5")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     desc, n, build = WORKLOADS[args.workload]
