@@ -49,6 +49,7 @@ __device__ __forceinline__ double max0(double x)
 // ---------------------------------------------------------------------------------------------
 // ProductTwoCoin -- src/cfmms.jl:125-140
 // ---------------------------------------------------------------------------------------------
+
 struct ProductOps {
     static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = false;
