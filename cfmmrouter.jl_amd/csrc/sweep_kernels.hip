@@ -565,9 +565,10 @@ __device__ __forceinline__ bool stage_prices(const SweepArgs& a, const SweepLds&
 // trip behind the staging barrier); otherwise the caller has staged already.
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS, bool STAGE>
 __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
-                                              int sub_tid, int sub_block)
+                                              int sub_tid, int sub_block, bool& live_out)
 {
     double acc = 0.0;
+    live_out = true;
     // `valid` is false only for wave-cooperative families, whose lanes without a pool still have to
     // take part in the wavefront-wide phases of solve_wave.
     auto process = [&](const typename Ops::Raw& raw_in, int64_t i, bool valid) {
@@ -655,6 +656,7 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         if constexpr (STAGE) {
             if (!stage_prices<BLOCK, GBINS>(a, L)) {       // a pre-armed launch that is not needed (or gave up)
                 ok = false;
+                live_out = false;
                 acc = __builtin_nan("");                   // poisons the dual column should anyone fold this row
             }
         }
@@ -679,6 +681,7 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         bool live = true;
         if constexpr (STAGE) live = stage_prices<BLOCK, GBINS>(a, L);
         if (!live) acc = __builtin_nan("");
+        live_out = live;
         const int64_t tile_pools = (int64_t)sub_block * U;
         const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
         const int64_t mine = live && bid < n_tiles ? (n_tiles - bid + nblocks - 1) / nblocks : 0;
@@ -704,7 +707,7 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
 // Block epilogue: fold the dual scalar (lanes by wave shuffles, waves through LDS, fixed order), fold
 // the bin copies in a fixed order and write the block's partial row.
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id)
+__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id, bool live = true)
 {
     constexpr int kBlock = BLOCK;
     constexpr int kWaves = BLOCK / 64;
@@ -717,7 +720,9 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
-    const bool publish = !GBINS && a.fold_blocks > 0;    // the row is folded inside THIS launch
+    // the row is folded inside THIS launch (not for a cancelled pre-armed launch: nobody will fold, and the arrival
+    // counters must stay zero for the next launch)
+    const bool publish = !GBINS && a.fold_blocks > 0 && live;
     for (int j = tid; j < n_cols; j += kBlock) {
         double s = L.bins[j];
         for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
@@ -746,11 +751,13 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
 // One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
 // row goes to partials[row_id].
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
-__device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
+__device__ __forceinline__ bool sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
-    const double acc = sweep_tiles<Ops, MAT, U, BLOCK, GBINS, true>(ops, a, L, bid, nblocks, (int)threadIdx.x, BLOCK);
-    finish_row<BLOCK, GBINS>(a, L, acc, row_id);
+    bool live;
+    const double acc = sweep_tiles<Ops, MAT, U, BLOCK, GBINS, true>(ops, a, L, bid, nblocks, (int)threadIdx.x, BLOCK, live);
+    finish_row<BLOCK, GBINS>(a, L, acc, row_id, live);
+    return live;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -873,13 +880,22 @@ template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
     if constexpr (!GBINS) {
-        if ((int)blockIdx.x < a.fold_blocks) {
+        if (!a.fold_tail && (int)blockIdx.x < a.fold_blocks) {
             fold_role<BLOCK>(a, (int)gridDim.x - a.fold_blocks);
             return;
         }
     }
-    const int fb = GBINS ? 0 : a.fold_blocks;
-    sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
+    const int fb = (GBINS || a.fold_tail) ? 0 : a.fold_blocks;
+    const bool live = sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
+    if constexpr (!GBINS) {
+        // tail fold: the first fold_blocks blocks of the grid, done with their own pools, wait for everybody's row
+        // (all blocks of the grid are resident at once -- checked by the host -- so nobody waits for a block that
+        // cannot start) and fold 8 columns each: no second launch, no blocks that only wait
+        if (a.fold_tail && live && (int)blockIdx.x < a.fold_blocks) {
+            __syncthreads();
+            fold_role<BLOCK>(a, (int)gridDim.x);
+        }
+    }
 }
 
 // Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
@@ -888,7 +904,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
-    const int fb = GBINS ? 0 : ma.common.fold_blocks;
+    const bool tail = !GBINS && ma.common.fold_tail != 0;
+    const int fb = (GBINS || tail) ? 0 : ma.common.fold_blocks;
     if (!GBINS && (int)blockIdx.x < fb) {
         fold_role<BLOCK>(ma.common, (int)gridDim.x - fb);
         return;
@@ -914,18 +931,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         const SweepLds L = carve_lds<BLOCK, GBINS>(a);
         (void)stage_prices<BLOCK, GBINS>(a, L);           // never armed (host side: wave_split excludes arming)
         double acc = 0.0;
+        bool ws_live;
         switch (sg.kind) {                                // wavefront-uniform
         case 0:
-            acc = sweep_tiles<ProductOps, MAT, 1, BLOCK, GBINS, false>(ProductOps{sg.pools.p}, a, L, bidx, G, sub_tid, sub_block);
+            acc = sweep_tiles<ProductOps, MAT, 1, BLOCK, GBINS, false>(ProductOps{sg.pools.p}, a, L, bidx, G, sub_tid, sub_block, ws_live);
             break;
         case 1:
-            acc = sweep_tiles<GeoMeanLogOps, MAT, 1, BLOCK, GBINS, false>(GeoMeanLogOps{sg.pools.g}, a, L, bidx, G, sub_tid, sub_block);
+            acc = sweep_tiles<GeoMeanLogOps, MAT, 1, BLOCK, GBINS, false>(GeoMeanLogOps{sg.pools.g}, a, L, bidx, G, sub_tid, sub_block, ws_live);
             break;
         default:
             {
                 UniV3CoopOps ops;
                 ops.p = sg.pools.u;
-                acc = sweep_tiles<UniV3CoopOps, MAT, 1, BLOCK, GBINS, false>(ops, a, L, bidx, G, sub_tid, sub_block);
+                acc = sweep_tiles<UniV3CoopOps, MAT, 1, BLOCK, GBINS, false>(ops, a, L, bidx, G, sub_tid, sub_block, ws_live);
             }
             break;
         }
@@ -960,21 +978,26 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.Lambda = sg.Lambda;
     a.Over = sg.Over;
     a.gflow = sg.gflow;
+    bool live;
     switch (sg.kind) {
     case 0:
-        sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
+        live = sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
         break;
     case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
-        sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
+        live = sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
         {   // the cooperative variant serves both shallow and deep segments here (no register cost:
             // the fused kernel's footprint is set by the GeometricMean branch)
             UniV3CoopOps ops;
             ops.p = sg.pools.u;
-            sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
+            live = sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
         }
         break;
+    }
+    if (tail && live && (int)blockIdx.x < ma.common.fold_blocks) {   // tail fold, see sweep_kernel
+        __syncthreads();
+        fold_role<BLOCK>(ma.common, (int)gridDim.x);
     }
 }
 
@@ -1115,9 +1138,21 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
 // the command processor at the kernel's first and last wavefront (hipExtLaunchKernel): that is the
 // kernel's own execution span, the quantity rocprofv3 reports, without the ~2.5 us that a
 // hipEventRecord / launch / hipEventRecord bracket adds.
+static thread_local int* t_occupancy = nullptr;   // LaunchCfg::occupancy of the launch being dispatched
+
 template <class K, class... A>
 static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, A... args)
 {
+    if (t_occupancy) {   // query only: how many blocks of exactly this kernel / block size / LDS size fit one CU
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), (int)b.x, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            nb = 0;
+        }
+        *t_occupancy = nb;
+        t_occupancy = nullptr;
+        return;
+    }
     if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, (std::uint32_t)lds, s, e0, e1, 0u, args...);
     else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
 }
@@ -1150,7 +1185,8 @@ static hipError_t set_lds_attr(size_t bytes)
 template <int B>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid + (ma.common.gflow ? 0 : ma.common.fold_blocks)), b(B);
+    dim3 g(c.grid + ((ma.common.gflow || ma.common.fold_tail) ? 0 : ma.common.fold_blocks)), b(B);
+    t_occupancy = c.occupancy;
     if (ma.common.gflow) {
         if (mat) launch_k(&sweep_multi<true, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
         else launch_k(&sweep_multi<false, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
@@ -1192,7 +1228,8 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
 template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid + (a.gflow ? 0 : a.fold_blocks)), b(B);
+    dim3 g(c.grid + ((a.gflow || a.fold_tail) ? 0 : a.fold_blocks)), b(B);
+    t_occupancy = c.occupancy;
     hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
     if (a.gflow) { // large-market mode, one pool per lane per tile only
         if (mat) launch_k(&sweep_kernel<Ops, true, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);

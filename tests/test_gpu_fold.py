@@ -17,9 +17,9 @@ from helpers import oracle_sweep, rel_to_max
 pytestmark = pytest.mark.gpu
 
 
-def _pair(n, batches, **opts):
+def _pair(n, batches, mode=1, **opts):
     a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
-    a.ctx.set_option("inline_fold", 1)
+    a.ctx.set_option("inline_fold", mode)
     b.ctx.set_option("inline_fold", 0)
     for k, v in opts.items():
         a.ctx.set_option(k, v)
@@ -27,8 +27,11 @@ def _pair(n, batches, **opts):
     return a, b
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["extra_blocks", "tail"])
 @pytest.mark.parametrize("shape", ["config2", "config3mini", "config4mini", "bounded", "tiny", "n1024"])
-def test_inline_fold_bitwise_equals_separate_fold(shape):
+def test_inline_fold_bitwise_equals_separate_fold(shape, mode):
+    """mode 1: extra blocks in front of the grid only fold; mode 2: the first blocks of the grid fold after their own
+    share of the sweep (no extra blocks; the library checks that the whole grid is resident at once)."""
     if shape == "config2":
         n, batches = 64, [synth.product_pools(100_000, 64, seed=3)]
     elif shape == "config3mini":
@@ -41,7 +44,7 @@ def test_inline_fold_bitwise_equals_separate_fold(shape):
         n, batches = 2, [synth.product_pools(3, 2, seed=7)]
     else:
         n, batches = 1024, [synth.product_pools(70_000, 1024, seed=8)]
-    a, b = _pair(n, batches)
+    a, b = _pair(n, batches, mode)
     try:
         rng = np.random.default_rng(11)
         for it in range(40):   # back to back: the fold blocks re-read row addresses they read one sweep ago
