@@ -582,7 +582,8 @@ int ensure_geometry(cfmm_ctx* c)
         (void)hipFree(c->d_partials);
         c->d_partials = nullptr;
         c->rows_cap = 0;
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials), (size_t)rows * row_width(c) * sizeof(double)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials), 2 * (size_t)rows * row_width(c) * sizeof(double)));   // x2: self-validating rows (inline_fold = 3) hold 16 bytes per entry
+        HIP_TRY(c, hipMemset(c->d_partials, 0, 2 * (size_t)rows * row_width(c) * sizeof(double)));
         c->rows_cap = rows;
     }
     if (trades > c->trade_cap) {
@@ -630,7 +631,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     // occupancy below, launch by launch.
     const bool fold_ok = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
                          c->n <= kMaxFoldTokens && c->d_sync != nullptr;
-    const bool want_tail = fold_ok && c->opt_inline_fold == 2 && c->opt_wave_split == 0;
+    const bool want_tail = fold_ok && (c->opt_inline_fold == 2 || c->opt_inline_fold == 3) && c->opt_wave_split == 0;
     bool inline_fold = fold_ok && c->opt_inline_fold == 1 && arm_seq == 0;
     const unsigned long long* arm_word = arm_seq ? reinterpret_cast<const unsigned long long*>(c->d_arm + c->n_pad) : nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
@@ -690,7 +691,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         }
         if (tail) inline_fold = true;
         a.fold_blocks = inline_fold ? fold_blocks : 0;
-        a.fold_tail = tail ? 1 : 0;
+        a.fold_tail = tail ? (c->opt_inline_fold == 3 ? 2 : 1) : 0;
+        a.fold_tag = (unsigned)(c->sweep_count % 0xffffffffull) + 1u;
         a.sync = c->d_sync;
         a.fold_out = d_out;
         a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;

@@ -97,6 +97,11 @@ struct SweepArgs {
     int fold_blocks;
     int fold_tail;               // 1: no extra blocks -- the first fold_blocks blocks of the grid fold AFTER their own share of the
                                  //    sweep (every block of the grid must be resident at once: the host checks the occupancy)
+                                 // 2: the same, over SELF-VALIDATING rows: every row entry is two 8-byte granules {fold_tag,
+                                 //    32 bits of the double}, written through by the sweeping block and re-read by the folding
+                                 //    blocks until both carry this launch's tag -- no drain, no arrival counter, no ticket
+                                 //    (partials then holds [grid][n+1] 16-byte entries)
+    unsigned fold_tag;           // never 0
     unsigned* sync;
     double* fold_out;            // [n+1] {Ψ, acc}
     unsigned long long* host_flag; // optional (mapped pinned host memory): set to host_seq by the last fold block

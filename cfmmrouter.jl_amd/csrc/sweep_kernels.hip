@@ -719,6 +719,30 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     __syncthreads();
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
+    if (!GBINS && a.fold_tail == 2) {
+        // self-validating row: entry j = {tag | low half, tag | high half} of the double, one 16-byte write-through
+        // store (each 8-byte half is valid on its own, so a torn 16-byte store is harmless); nothing to drain or count
+        if (live) {
+            double2* row16 = reinterpret_cast<double2*>(a.partials) + (size_t)row_id * (n_cols + 1);
+            const unsigned long long tag = (unsigned long long)a.fold_tag << 32;
+            auto put = [&](int j, double s) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+                store_pair(row16 + j, __longlong_as_double((long long)(tag | (bits & 0xffffffffull))),
+                           __longlong_as_double((long long)(tag | (bits >> 32))), 2);
+            };
+            for (int j = tid; j < n_cols; j += kBlock) {
+                double s = L.bins[j];
+                for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
+                put(j, s);
+            }
+            if (tid == 0) {
+                double s = L.wsum[0];
+                for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
+                put(n_cols, s);
+            }
+        }
+        return;
+    }
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
     // the row is folded inside THIS launch (not for a cancelled pre-armed launch: nobody will fold, and the arrival
     // counters must stay zero for the next launch)
@@ -876,6 +900,82 @@ __device__ __forceinline__ void fold_role(const SweepArgs& a, int nprod)
     fold_finish(tsum, ok, n1, a.fold_out, a.sync, a.fold_blocks, true, a.host_flag, a.host_seq);
 }
 
+// Tail fold over self-validating rows (SweepArgs::fold_tail == 2).  Same lane -> (row-lane, column) map, same
+// batches and the same summation order as fold_columns, so the result is bit-identical to reduce_partials; the only
+// difference is how a row entry becomes readable: the lane re-reads its two granules (agent-scope loads, which miss
+// the XCD's L2) until both carry this launch's tag.  Bounded by wall-clock time; a lane that gives up poisons the
+// block's outputs with NaN.
+template <int BLOCK>
+__device__ __forceinline__ void fold_role_tagged(const SweepArgs& a, int nprod)
+{
+    extern __shared__ double lds[];
+    double* red = lds;                                   // [BLOCK/64][kReduceCols]
+    constexpr int kRowLanes = BLOCK / kReduceCols;
+    constexpr int kWaves = BLOCK / 64;
+    constexpr int kBatch = 8;
+    const int n1 = a.n + 1;
+    const int c = threadIdx.x % kReduceCols;
+    const int r = threadIdx.x / kReduceCols;
+    const int col = blockIdx.x * kReduceCols + c;
+    const unsigned long long tag = (unsigned long long)a.fold_tag << 32;
+    const unsigned long long hi_mask = 0xffffffff00000000ull;
+    const long long t0 = (long long)wall_clock64();
+    const long long limit = 200000000ll;                 // 2 s of the 100 MHz wall clock
+    bool ok = true;
+    double s = 0.0;
+    if (col < n1) {
+        const unsigned long long* base = reinterpret_cast<const unsigned long long*>(a.partials) + 2 * (size_t)col;
+        const size_t pitch = 2 * (size_t)n1;             // granules per row
+        auto issue = [&](int row, unsigned long long& g0, unsigned long long& g1) {
+            const unsigned long long* g = base + (size_t)row * pitch;
+            g0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // one batch: up to kBatch rows of this lane, ALL in flight at once; the entries that do not carry the tag yet
+        // are re-read together (a row-by-row wait would pay one memory round trip per row after the last arrival)
+        auto batch = [&](int row0, int cnt) {
+            unsigned long long g0[kBatch], g1[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)
+                if (b < cnt) issue(row0 + b * kRowLanes, g0[b], g1[b]);
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b)
+                    if (b < cnt) all = all && (g0[b] & hi_mask) == tag && (g1[b] & hi_mask) == tag;
+                if (all) break;
+                if ((long long)wall_clock64() - t0 > limit) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b)
+                    if (b < cnt && ((g0[b] & hi_mask) != tag || (g1[b] & hi_mask) != tag)) issue(row0 + b * kRowLanes, g0[b], g1[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b)   // ascending rows: the summation order of fold_columns
+                if (b < cnt) s += __longlong_as_double((long long)((g0[b] & 0xffffffffull) | (g1[b] << 32)));
+        };
+        int row = r;
+        for (; row + (kBatch - 1) * kRowLanes < nprod; row += kBatch * kRowLanes) batch(row, kBatch);
+        if (row < nprod) batch(row, (nprod - row + kRowLanes - 1) / kRowLanes);
+    }
+#pragma unroll
+    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int* bad = reinterpret_cast<int*>(lds + kWaves * kReduceCols);   // dynamic LDS only: the kernels' LDS ceiling is all dynamic
+    if (threadIdx.x == 0) *bad = 0;
+    __syncthreads();
+    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
+    if (!ok) *bad = 1;
+    __syncthreads();
+    const bool all_ok = *bad == 0;
+    double tsum = 0.0;
+    if (threadIdx.x < kReduceCols) {
+        tsum = red[c];
+        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
+    }
+    fold_finish(tsum, all_ok, n1, a.fold_out, a.sync, a.fold_blocks, false, a.host_flag, a.host_seq);
+}
+
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
@@ -893,7 +993,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
         // cannot start) and fold 8 columns each: no second launch, no blocks that only wait
         if (a.fold_tail && live && (int)blockIdx.x < a.fold_blocks) {
             __syncthreads();
-            fold_role<BLOCK>(a, (int)gridDim.x);
+            if (a.fold_tail == 2) fold_role_tagged<BLOCK>(a, (int)gridDim.x);
+            else fold_role<BLOCK>(a, (int)gridDim.x);
         }
     }
 }
@@ -997,7 +1098,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     }
     if (tail && live && (int)blockIdx.x < ma.common.fold_blocks) {   // tail fold, see sweep_kernel
         __syncthreads();
-        fold_role<BLOCK>(ma.common, (int)gridDim.x);
+        if (ma.common.fold_tail == 2) fold_role_tagged<BLOCK>(ma.common, (int)gridDim.x);
+        else fold_role<BLOCK>(ma.common, (int)gridDim.x);
     }
 }
 

@@ -27,11 +27,12 @@ def _pair(n, batches, mode=1, **opts):
     return a, b
 
 
-@pytest.mark.parametrize("mode", [1, 2], ids=["extra_blocks", "tail"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["extra_blocks", "tail", "tail_tagged_rows"])
 @pytest.mark.parametrize("shape", ["config2", "config3mini", "config4mini", "bounded", "tiny", "n1024"])
 def test_inline_fold_bitwise_equals_separate_fold(shape, mode):
     """mode 1: extra blocks in front of the grid only fold; mode 2: the first blocks of the grid fold after their own
-    share of the sweep (no extra blocks; the library checks that the whole grid is resident at once)."""
+    share of the sweep (no extra blocks; the library checks that the whole grid is resident at once); mode 3: the same
+    over self-validating rows (every entry carries the launch's tag: no drain, no arrival counters, no ticket)."""
     if shape == "config2":
         n, batches = 64, [synth.product_pools(100_000, 64, seed=3)]
     elif shape == "config3mini":
