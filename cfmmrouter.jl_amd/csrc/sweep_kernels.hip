@@ -933,30 +933,28 @@ __device__ __forceinline__ void fold_role_tagged(const SweepArgs& a, int nprod)
         };
         // one batch: up to kBatch rows of this lane, ALL in flight at once; the entries that do not carry the tag yet
         // are re-read together (a row-by-row wait would pay one memory round trip per row after the last arrival)
-        auto batch = [&](int row0, int cnt) {
-            unsigned long long g0[kBatch], g1[kBatch];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b)
-                if (b < cnt) issue(row0 + b * kRowLanes, g0[b], g1[b]);
+        auto batch = [&](int row0, auto count) {
+            constexpr int CNT = decltype(count)::value;
+            unsigned long long g0[CNT], g1[CNT];
+            for (int b = 0; b < CNT; ++b) issue(row0 + b * kRowLanes, g0[b], g1[b]);
             for (;;) {
                 bool all = true;
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b)
-                    if (b < cnt) all = all && (g0[b] & hi_mask) == tag && (g1[b] & hi_mask) == tag;
+                for (int b = 0; b < CNT; ++b) all &= ((g0[b] & hi_mask) == tag) & ((g1[b] & hi_mask) == tag);
                 if (all) break;
                 if ((long long)wall_clock64() - t0 > limit) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b)
-                    if (b < cnt && ((g0[b] & hi_mask) != tag || (g1[b] & hi_mask) != tag)) issue(row0 + b * kRowLanes, g0[b], g1[b]);
+                for (int b = 0; b < CNT; ++b)
+                    if ((g0[b] & hi_mask) != tag || (g1[b] & hi_mask) != tag) issue(row0 + b * kRowLanes, g0[b], g1[b]);
             }
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b)   // ascending rows: the summation order of fold_columns
-                if (b < cnt) s += __longlong_as_double((long long)((g0[b] & 0xffffffffull) | (g1[b] << 32)));
+            for (int b = 0; b < CNT; ++b)   // ascending rows: the summation order of fold_columns
+                s += __longlong_as_double((long long)((g0[b] & 0xffffffffull) | (g1[b] << 32)));
         };
         int row = r;
-        for (; row + (kBatch - 1) * kRowLanes < nprod; row += kBatch * kRowLanes) batch(row, kBatch);
-        if (row < nprod) batch(row, (nprod - row + kRowLanes - 1) / kRowLanes);
+        for (; row + (kBatch - 1) * kRowLanes < nprod; row += kBatch * kRowLanes) batch(row, std::integral_constant<int, kBatch>());
+        // the remaining (< kBatch) rows of this lane, still in ascending order: 4 + 2 + 1
+        if (row + 3 * kRowLanes < nprod) { batch(row, std::integral_constant<int, 4>()); row += 4 * kRowLanes; }
+        if (row + kRowLanes < nprod) { batch(row, std::integral_constant<int, 2>()); row += 2 * kRowLanes; }
+        if (row < nprod) batch(row, std::integral_constant<int, 1>());
     }
 #pragma unroll
     for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
