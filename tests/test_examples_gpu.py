@@ -59,3 +59,29 @@ def test_sequential_sharded_example(devices, capsys):
     first, second = sequential_sharded.main(devices)
     assert "round 2" in capsys.readouterr().out
     assert first > 1e3 and abs(second) <= 1e-6 * first      # the market is cleared after one pass
+
+
+@pytest.mark.parametrize("solver", ["scipy", "native"])
+def test_chain_snapshot_example(solver, capsys):
+    """on-chain units -> reference pool types -> route! on the device.  Checked: the trades and netflows at the
+    device's v* against a CPU sweep at the same prices (the parity statement), and the profit against the CPU
+    restatement's own route! (two L-BFGS-B runs on a stiff 17-pool market agree on the objective, not on every
+    component of a flat optimum)."""
+    import chain_snapshot
+    from helpers import oracle_sweep
+    tokens, Ψ, v, batches, D, L = chain_snapshot.main(solver)
+    assert "Profit" in capsys.readouterr().out and len(tokens) == 5
+    usd = {"USDC": 1.0, "DAI": 1.0, "USDT": 1.0, "FRAX": 0.998, "LUSD": 1.004}
+    c = np.array([usd[t] for t in tokens])
+    Do, Lo, psio, _ = oracle_sweep(batches, 5, v)
+    m_prod, m_geo = len(batches[0]), len(batches[1])
+    geo = slice(m_prod, m_prod + m_geo)
+    exact = np.r_[0:m_prod, m_prod + m_geo:len(D)]                   # ProductTwoCoin and UniV3 rows: bit for bit
+    np.testing.assert_array_equal(D[exact], Do[exact])
+    np.testing.assert_array_equal(L[exact], Lo[exact])
+    np.testing.assert_allclose(D[geo], Do[geo], rtol=0, atol=1e-12 * np.max(batches[1].R))
+    scale = max(np.max(b.R) if hasattr(b, "R") and b.R is not None else 0.0 for b in batches[:2])   # gross flows are of the reserves' order; the net is tiny
+    assert np.max(np.abs(Ψ - psio)) <= 1e-12 * scale
+    ref = orc.route_oracle(oracle_objective(cr.LinearNonnegative(c)), oracle_poolset(batches, 5), v0=c.copy())
+    assert abs(c @ Ψ - c @ ref["psi"]) <= 1e-5 * abs(c @ ref["psi"]) and c @ Ψ > 10
+    assert np.all(Ψ >= -1e-3 * np.max(np.abs(Ψ)))
