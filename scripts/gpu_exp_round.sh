@@ -1,5 +1,7 @@
-mkdir -p gpurun_out; rm -f gpurun_out/exp_tail.txt
-timeout 500 python -m pytest tests/test_gpu_fold.py tests/test_gpu_armed.py -m gpu -x -q 2>&1 | tail -2
-for w in config3 product1m; do
-timeout 300 python scripts/exp.py $w "inline_fold=0" "inline_fold=3" "inline_fold=0" "inline_fold=3" 2>&1 | grep -v "amdgpu.ids\|^#" | sed "s/^/$w /" | tee -a gpurun_out/exp_tail.txt
-done
+mkdir -p gpurun_out; rm -rf gpurun_out/rt_*; R=$PWD
+cd /tmp && export TMPDIR=/tmp
+for w in config3 config5; do for a in 1 0; do
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/rt_${w}_$a -o rt -- python $R/scripts/route_once.py $w $a > $R/gpurun_out/rt_${w}_$a.log 2>&1 < /dev/null
+tail -1 $R/gpurun_out/rt_${w}_$a.log
+python $R/scripts/route_kernel_gaps.py $R/gpurun_out/rt_${w}_$a "$w a=$a" | tee -a $R/gpurun_out/route_kernel_gaps.txt
+done; done
