@@ -166,6 +166,8 @@ struct cfmm_ctx {
     uint64_t flag_seq = 0;        // host-visible completion flag: value the NEXT flagged sweep will raise
     bool last_inline = false;     // the latest enqueue_sweep folded inside the sweep launch
     bool last_flagged = false;    // ... and raises the host flag (the caller may poll it instead of the stream)
+    size_t gran_off = 0;          // first output granule in h_stage / d_stage (doubles)
+    bool last_granules = false;   // ... in the form of self-validating output granules (no flag word: the data carries flag_seq)
     std::vector<double> last_out; // psi..., acc of the latest host-pointer sweep
     std::vector<double> trade_v;  // v of the latest MATERIALISING host-pointer sweep (empty: none / device-pointer sweep)
     bool have_out = false;
@@ -198,6 +200,8 @@ struct cfmm_ctx {
     uint64_t sweep_count = 0;
     int64_t opt_inline_fold = 0;   // 1: partial rows are folded inside the sweep launch (single-launch evaluations, n <= kMaxFoldTokens);
                                    //    measured 1-3 us per step SLOWER than the separate fold launch, kept as an option
+    int64_t opt_host_granules = 1; // 1: a flagged sweep returns {psi, acc} to the host as self-validating 8-byte granules (tag + half
+                                   //    of a double) that the host re-reads until complete, instead of outputs + drain + ticket + flag
     int64_t opt_armed = 1;         // 1: cfmm_route enqueues evaluation k+1 while evaluation k runs; its blocks wait on the device for
                                    //    the host to write v through the PCIe BAR (hides the launch latency: -4..-5 us per evaluation)
     int64_t opt_arm_timeout_ms = 2000; // bound of that wait
@@ -636,6 +640,14 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const unsigned long long* arm_word = arm_seq ? reinterpret_cast<const unsigned long long*>(c->d_arm + c->n_pad) : nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
     const bool flagged = want_host_flag && !gb && (sharded || c->rows_total > 0) && c->d_sync != nullptr;
+    const bool granules = flagged && !sharded && c->opt_host_granules != 0;
+    // where the fold signals completion, and with what: the flag word + sequence number, or the granule array + tag
+    unsigned long long* const flag_ptr = !flagged ? nullptr
+                                         : reinterpret_cast<unsigned long long*>(c->d_stage + (granules ? c->gran_off : (size_t)(2 * c->n + 1)));
+    auto next_seq = [&]() -> unsigned long long {
+        ++c->flag_seq;
+        return granules ? (kHostGranules | (c->flag_seq % 0xffffffffull + 1ull)) : c->flag_seq;
+    };
     HIP_TRY(c, hipSetDevice(c->device));
     size_t group_index = 0;
     for (const Group& g : c->groups) {
@@ -695,8 +707,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.fold_tag = (unsigned)(c->sweep_count % 0xffffffffull) + 1u;
         a.sync = c->d_sync;
         a.fold_out = d_out;
-        a.host_flag = flagged && inline_fold ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr;
-        a.host_seq = flagged && inline_fold ? ++c->flag_seq : 0;
+        a.host_flag = flagged && inline_fold ? flag_ptr : nullptr;
+        a.host_seq = flagged && inline_fold ? next_seq() : 0;
         a.arm_word = arm_word;
         a.arm_seq = arm_seq;
         a.arm_timeout = std::min<long long>(std::max<long long>(c->opt_arm_timeout_ms, 1), 10000) * 100000ll;   // ms -> ticks of the 100 MHz wall clock, at most 10 s
@@ -760,6 +772,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     }
     c->last_inline = inline_fold;
     c->last_flagged = flagged;
+    c->last_granules = granules;
     hipEvent_t ra = nullptr, rb = nullptr;
     if (timed) {
         ra = take_event(c);
@@ -792,8 +805,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                               c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->d_partials, (int)c->rows_total, c->stream);
         } else {
             e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, c->groups.back().block, ra, rb,
-                              c->d_sync, flagged ? reinterpret_cast<unsigned long long*>(c->d_stage + 2 * c->n + 1) : nullptr,
-                              flagged ? ++c->flag_seq : 0, ArmWord{arm_word, arm_seq});
+                              c->d_sync, flag_ptr, flagged ? next_seq() : 0, ArmWord{arm_word, arm_seq});
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
     } else {
@@ -846,6 +858,24 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
     return CFMM_OK;
 }
 
+// Output granules of the flagged sweep with sequence number `seq` (fold_finish, kHostGranules): true once all 2(n+1)
+// carry its tag; the doubles are then reassembled into the {Ψ, acc} slots of the staging buffer.
+bool granules_arrived(cfmm_ctx* c, uint64_t seq)
+{
+    const unsigned long long tag = seq % 0xffffffffull + 1ull;
+    const volatile unsigned long long* g = reinterpret_cast<const volatile unsigned long long*>(c->h_stage + c->gran_off);
+    const int n1 = c->n + 1;
+    if ((g[2 * n1 - 1] >> 32) != tag || (g[0] >> 32) != tag) return false;   // cheap rejects: last and first granule
+    double* h_out = c->h_stage + c->n;
+    for (int j = 0; j < n1; ++j) {
+        const unsigned long long a = g[2 * j], b = g[2 * j + 1];
+        if ((a >> 32) != tag || (b >> 32) != tag) return false;
+        const unsigned long long bits = (a & 0xffffffffull) | (b << 32);
+        std::memcpy(h_out + j, &bits, sizeof(double));
+    }
+    return true;
+}
+
 // {Ψ, acc} have arrived in the pinned staging buffer: take them over into last_out.
 int take_host_out(cfmm_ctx* c)
 {
@@ -878,7 +908,7 @@ int host_sweep_end(cfmm_ctx* c)
         volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_stage + 2 * c->n + 1);
         const unsigned long long want = c->flag_seq;
         for (long spins = 0; spins < 400000000L; ++spins) {
-            if (*flag == want) { flag_seen = true; break; }
+            if (c->last_granules ? granules_arrived(c, want) : *flag == want) { flag_seen = true; break; }
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -893,6 +923,10 @@ int host_sweep_end(cfmm_ctx* c)
     } else {
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (!flag_seen && c->last_flagged && c->last_granules && !granules_arrived(c, c->flag_seq)) {
+        c->have_out = false;
+        return fail(c, CFMM_ERR_STATE, "the sweep retired without delivering its outputs");
     }
     return take_host_out(c);
 }
@@ -959,8 +993,9 @@ int armed_eval(cfmm_ctx* c, const double* v)
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_stage + 2 * c->n + 1);
     bool seen = false;
     const auto t0 = std::chrono::steady_clock::now();
+    const bool by_granules = c->last_granules;
     for (long spins = 0;; ++spins) {
-        if (*flag == want) { seen = true; break; }
+        if (by_granules ? granules_arrived(c, want) : *flag == want) { seen = true; break; }
         __builtin_ia32_pause();
         if ((spins & 0xffff) == 0xffff &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >
@@ -1330,9 +1365,12 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     c->stream = c->own_stream;
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_v), (size_t)c->n * sizeof(double)));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_out), (size_t)(c->n + 1) * sizeof(double)));
-    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)(2 * c->n + 2) * sizeof(double),
-                            hipHostMallocMapped));
-    std::memset(c->h_stage, 0, (size_t)(2 * c->n + 2) * sizeof(double));
+    // [n] v, [n+1] {psi, acc}, completion flag, padding to a 128-byte boundary, then the output granules: 16 per fold
+    // block = 2 per column, columns padded to a multiple of 8 (see fold_finish / kHostGranules)
+    c->gran_off = (size_t)((2 * c->n + 2 + 15) & ~15);
+    const size_t stage_words = c->gran_off + 2 * (size_t)((c->n + 1 + 7) & ~7);
+    HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), stage_words * sizeof(double), hipHostMallocMapped));
+    std::memset(c->h_stage, 0, stage_words * sizeof(double));
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->d_sync), (size_t)kSyncWords * sizeof(unsigned)));
     HIP_TRY_C(hipMemset(c->d_sync, 0, (size_t)kSyncWords * sizeof(unsigned)));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_stage), c->h_stage, 0) != hipSuccess) {
@@ -1474,6 +1512,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     if (!std::strcmp(key, "pack")) return &c->opt_pack;
     if (!std::strcmp(key, "compact_trades")) return &c->opt_compact_trades;
     if (!std::strcmp(key, "armed")) return &c->opt_armed;
+    if (!std::strcmp(key, "host_granules")) return &c->opt_host_granules;
     if (!std::strcmp(key, "arm_timeout_ms")) return &c->opt_arm_timeout_ms;
     if (!std::strcmp(key, "xcd_map")) return &c->opt_xcd_map;
     if (!std::strcmp(key, "cost_geomean")) return &c->opt_cost_geomean;

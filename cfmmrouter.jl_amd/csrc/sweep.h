@@ -117,6 +117,7 @@ struct SweepArgs {
     long long arm_timeout;
 };
 constexpr unsigned long long kArmCancel = 1ull << 63;
+constexpr unsigned long long kHostGranules = 1ull << 63;   // SweepArgs::host_seq / launch_reduce: outputs as tagged granules (fold_finish)
 constexpr int kArriveShards = 16;    // arrival counters (one 128-B line each): block b arrives on shard b % 16
 constexpr int kSyncStride = 32;      // uint32 words per shard line
 constexpr int kSyncWords = (kArriveShards + 1) * kSyncStride;   // + the fold blocks' own "done" ticket line

@@ -837,13 +837,32 @@ __device__ __forceinline__ double fold_columns(const double* partials, int rows,
 // outputs live in mapped host memory and are written with system-scope (write-through) stores that
 // every block drains before it takes its ticket, so the flag -- a later posted write on the same
 // PCIe path -- cannot overtake them.
+// host_seq with kHostGranules set: host_flag points to 2·n1 8-byte words in mapped host memory and the outputs travel as
+// SELF-VALIDATING granules {tag = low 32 bits of host_seq, 32 bits of the double} (two per column, as between peers in
+// reduce_gather): the host re-reads them until all carry the tag -- no drain of the output stores, no ticket, no flag.
 __device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double* out, unsigned* sync, int fold_blocks,
                                             bool reset_arrivals, unsigned long long* host_flag,
                                             unsigned long long host_seq)
 {
     const int tid = threadIdx.x;
     const int col = blockIdx.x * kReduceCols + tid;
-    if (tid < kReduceCols && col < n1) {
+    const bool granules = host_flag != nullptr && (host_seq & kHostGranules) != 0;
+    if (granules) {
+        // the block's 8 columns leave as 16 granules = 128 contiguous, 128-byte aligned bytes written by ONE store
+        // instruction (lane 2c + h carries half h of column c): two full 64-byte lines on the PCIe side -- a line
+        // written in pieces costs a read-modify-write per piece at the host's memory controller (measured: 2x slower
+        // evaluations).  Columns past n1 travel as zeros so that the last block writes full lines too.
+        if (tid < 64) {
+            const double val = (tid < kReduceCols && col < n1) ? (ok ? tsum : __builtin_nan("")) : 0.0;
+            const long long bits = __shfl(__double_as_longlong(val), (tid >> 1) & (kReduceCols - 1), 64);
+            if (tid < 2 * kReduceCols) {
+                const unsigned long long tag = (host_seq & 0xffffffffull) << 32, u = (unsigned long long)bits;
+                __hip_atomic_store(host_flag + 2 * (size_t)blockIdx.x * kReduceCols + tid,
+                                   tag | ((tid & 1) ? (u >> 32) : (u & 0xffffffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        host_flag = nullptr;                               // nothing left to signal
+    } else if (tid < kReduceCols && col < n1) {
         const double val = ok ? tsum : __builtin_nan("");
         if (host_flag) __hip_atomic_store(out + col, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else out[col] = val;

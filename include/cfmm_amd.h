@@ -85,7 +85,8 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * per block, 2 = one per wavefront), "time_kernels", "nt_stores" (trade stores: 0 plain, 1 non-temporal, 2 write-through = default), "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
  * walks only, 1 wavefront-cooperative deep walks), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream),
  * "host_flag" (default 1: a zero-copy host-pointer sweep ends when the last fold block raises a flag in mapped host memory,
- * which the caller polls, instead of on the stream's completion signal), "inline_fold" (default 0; 1 = the partial rows are
+ * which the caller polls, instead of on the stream's completion signal), "host_granules" (default 1: such a sweep delivers {psi, acc} as self-validating 8-byte granules that the
+ * library re-reads until complete, instead of outputs + flag word; same values), "inline_fold" (default 0; 1 = the partial rows are
  * folded by extra blocks of the sweep launch instead of by a second launch, 2 = by the first blocks of the grid after their
  * own share of the sweep, when the whole grid is resident at once, 3 = as 2 over self-validating rows: 2-5 % faster than
  * the second launch on single-family markets, for a context that has the GPU to itself -- same bits in every form), "multi_threads"

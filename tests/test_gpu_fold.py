@@ -334,3 +334,30 @@ def test_compact_trade_records_are_lossless():
     Do, Lo, psi_o, _ = oracle_sweep([bp, bg, bu], n, v, nthreads=8)
     np.testing.assert_array_equal(res[1][2][:60_000], Do[:60_000])
     np.testing.assert_array_equal(res[1][2][100_000:], Do[100_000:])
+
+
+@pytest.mark.parametrize("n", [2, 7, 8, 64, 257, 1000])
+def test_output_granules_equal_flagged_outputs(n):
+    """Option "host_granules" (default 1): a host-pointer sweep returns {Ψ, acc} as self-validating 8-byte granules
+    (sequence tag + half of a double, 16 per fold block = two full 64-byte lines per store instruction) that the host
+    re-reads until all carry the tag, instead of outputs + drain + ticket + flag word.  Same values, any n_tokens
+    (the last fold block pads its lines with zero columns)."""
+    m = 40_000 if n > 2 else 300
+    batches = [synth.product_pools(m, n, seed=n)] + ([synth.geomean_pools(m // 2, n, seed=n + 1)] if n > 2 else [])
+    a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
+    a.ctx.set_option("host_granules", 1)
+    b.ctx.set_option("host_granules", 0)
+    try:
+        for it in range(25):
+            v = synth.sweep_prices(n, seed=300 + it)
+            for mat in (False, True):
+                pa = (a.find_arb if mat else a.eval)(v)
+                pb = (b.find_arb if mat else b.eval)(v)
+                if n > 600:    # the wavefronts of a block share one LDS bin copy: summation order is not fixed (DESIGN 7)
+                    assert rel_to_max(pa[0], pb[0]) <= 1e-14 and abs(pa[1] - pb[1]) <= 1e-12 * abs(pb[1])
+                else:
+                    np.testing.assert_array_equal(pa[0], pb[0])
+                    assert pa[1] == pb[1]
+    finally:
+        a.close()
+        b.close()
