@@ -86,7 +86,6 @@ struct Group {
     bool xcd_map = false;
     unsigned char pattern[32] = {0}, rank[32] = {0};
     int seg_w[kMaxMulti] = {0};
-    int resident[2] = {-1, -1};   // blocks of this launch's kernel one CU holds at once ([materialize]; -1: not asked yet)
 };
 
 } // namespace
@@ -158,7 +157,6 @@ struct cfmm_ctx {
     unsigned* d_sync = nullptr;   // [kSyncWords] arrival counters of the in-launch fold (zero between launches)
     // pre-armed evaluations of cfmm_route (sweep.h SweepArgs::arm_word): [n_pad] v, then the word, in FINE-GRAINED
     // device memory that the host writes through the PCIe BAR (null: no large BAR, or the self-check failed)
-    int n_cus = 0;                // compute units of the device (residency check of the tail fold)
     double* d_arm = nullptr;
     uint64_t arm_seq = 0;         // sequence number of the latest armed launch
     bool arm_pending = false;     // an armed launch is enqueued and has not been signalled or cancelled yet
@@ -629,14 +627,9 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool gb = global_bins(c);
     // One launch per evaluation: the partial rows are folded by extra blocks of that launch.
     const bool sharded = !c->peers.empty();   // fold + all-reduce over the peer mappings in one launch
-    // In-launch fold, two forms (option "inline_fold"): 1 = extra blocks in front of the grid that only fold; 2 = "tail
-    // fold": the first ceil((n+1)/8) blocks of the grid fold after their own share of the sweep -- every block of the
-    // grid must then be resident at once (a fold block waits for all rows), which is checked against the kernel's
-    // occupancy below, launch by launch.
-    const bool fold_ok = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
-                         c->n <= kMaxFoldTokens && c->d_sync != nullptr;
-    const bool want_tail = fold_ok && (c->opt_inline_fold == 2 || c->opt_inline_fold == 3) && c->opt_wave_split == 0;
-    bool inline_fold = fold_ok && c->opt_inline_fold == 1 && arm_seq == 0;
+    // One launch per evaluation (option "inline_fold"): the partial rows are folded by extra blocks of that launch.
+    const bool inline_fold = c->opt_inline_fold != 0 && !gb && !sharded && c->groups.size() == 1 && c->rows_total > 0 &&
+                             c->n <= kMaxFoldTokens && c->d_sync != nullptr && arm_seq == 0;
     const unsigned long long* arm_word = arm_seq ? reinterpret_cast<const unsigned long long*>(c->d_arm + c->n_pad) : nullptr;
     // host-visible completion flag: raised by the last fold block (of the sweep launch, or of reduce_partials)
     const bool flagged = want_host_flag && !gb && (sharded || c->rows_total > 0) && c->d_sync != nullptr;
@@ -670,41 +663,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.gflow = nullptr;
         a.nt_stores = (int)c->opt_nt_stores;
         a.reverse = c->opt_alternate != 0 ? (int)(c->sweep_count & 1) : 0;
-        const int fold_blocks = (c->n + 1 + kReduceCols - 1) / kReduceCols;
-        bool tail = false;
-        if (want_tail && fold_blocks <= g.grid) {
-            // residency: ask the runtime how many blocks of exactly this kernel fit one CU (cached per launch geometry)
-            int& res = const_cast<Group&>(g).resident[materialize ? 1 : 0];
-            if (res < 0) {
-                res = 0;
-                SweepArgs q = SweepArgs();
-                q.n = c->n;
-                q.n_pad = c->n_pad;
-                int nb = 0;
-                const size_t lds_q = sweep_lds_bytes(c->n_pad, bin_copies(c, g.block), g.block, a.need_logv, a.gtab_n);
-                if (g.multi) {
-                    MultiArgs mq;
-                    std::memset(&mq, 0, sizeof mq);
-                    LaunchCfg cq{g.block, g.grid, 1, lds_q, nullptr, nullptr, &nb};
-                    (void)launch_multi(mq, cq, materialize, c->stream);
-                } else {
-                    const Segment& sq = c->segs[(size_t)g.first];
-                    q.m = 1;
-                    LaunchCfg cq{g.block, g.grid, sq.unroll, lds_q, nullptr, nullptr, &nb};
-                    switch (sq.kind) {
-                    case CFMM_KIND_PRODUCT: (void)launch_sweep(ProductPools{}, q, cq, materialize, c->stream); break;
-                    case CFMM_KIND_GEOMEAN: { GeoMeanPools gp = GeoMeanPools(); gp.reference_order = (int)c->opt_geomean_exact; (void)launch_sweep(gp, q, cq, materialize, c->stream); } break;
-                    default: { UniV3Pools up = UniV3Pools(); up.deep = c->opt_univ3_coop < 0 ? sq.deep : (int)(c->opt_univ3_coop != 0); (void)launch_sweep(up, q, cq, materialize, c->stream); } break;
-                    }
-                }
-                res = nb;
-            }
-            tail = (int64_t)res * c->n_cus >= g.grid;
-        }
-        if (tail) inline_fold = true;
-        a.fold_blocks = inline_fold ? fold_blocks : 0;
-        a.fold_tail = tail ? (c->opt_inline_fold == 3 ? 2 : 1) : 0;
-        a.fold_tag = (unsigned)(c->sweep_count % 0xffffffffull) + 1u;
+        a.fold_blocks = inline_fold ? (c->n + 1 + kReduceCols - 1) / kReduceCols : 0;
         a.sync = c->d_sync;
         a.fold_out = d_out;
         a.host_flag = flagged && inline_fold ? flag_ptr : nullptr;
@@ -1345,7 +1304,6 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
 
     cfmm_ctx* c = new cfmm_ctx();
     c->device = device_id;
-    c->n_cus = prop.multiProcessorCount;
     c->n = n_tokens;
     c->n_pad = (n_tokens + 1) & ~1;
     auto bail = [&](int code) {

@@ -95,13 +95,6 @@ struct SweepArgs {
     // reduce_partials without a second launch.  sync = kSyncWords zero-initialised uint32 words,
     // left zero again by the launch.
     int fold_blocks;
-    int fold_tail;               // 1: no extra blocks -- the first fold_blocks blocks of the grid fold AFTER their own share of the
-                                 //    sweep (every block of the grid must be resident at once: the host checks the occupancy)
-                                 // 2: the same, over SELF-VALIDATING rows: every row entry is two 8-byte granules {fold_tag,
-                                 //    32 bits of the double}, written through by the sweeping block and re-read by the folding
-                                 //    blocks until both carry this launch's tag -- no drain, no arrival counter, no ticket
-                                 //    (partials then holds [grid][n+1] 16-byte entries)
-    unsigned fold_tag;           // never 0
     unsigned* sync;
     double* fold_out;            // [n+1] {Ψ, acc}
     unsigned long long* host_flag; // optional (mapped pinned host memory): set to host_seq by the last fold block
@@ -160,7 +153,6 @@ struct LaunchCfg {
     size_t lds_bytes;
     hipEvent_t ev_start = nullptr; // both set: the launch is timed by the command processor
     hipEvent_t ev_stop = nullptr;  // (hipExtLaunchKernel), i.e. the kernel's own execution span
-    int* occupancy = nullptr;      // set: do not launch; report how many blocks of this kernel one CU holds at once
 };
 
 hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,

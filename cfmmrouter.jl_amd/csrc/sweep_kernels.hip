@@ -538,21 +538,31 @@ __device__ __forceinline__ bool stage_prices(const SweepArgs& a, const SweepLds&
     const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
     const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
     const bool logs = !GBINS && a.need_logv;
-    for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
-    if (!GBINS)
-        for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
-    bool live = true;
     const bool armed = !GBINS && a.arm_word != nullptr;   // kernel argument: block-uniform
-    if (armed) {
-        if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
+    if (!armed) {
+        // prices first: their loads are in flight while the bins are cleared
+        for (int j = tid; j < n_stage; j += BLOCK) {
+            const double vj = a.v[j];
+            L.v_lds[j] = vj;
+            if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
+        }
+        for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+        if (!GBINS)
+            for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
         __syncthreads();
-        live = L.wsum[0] != 0.0;
+        return true;
     }
+    // pre-armed launch: everything that does not need the prices first, then the wait
+    for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+    for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
+    if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
+    __syncthreads();
+    const bool live = L.wsum[0] != 0.0;
     for (int j = tid; j < n_stage; j += BLOCK) {
-        // armed: the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
-        const double vj = armed ? __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.v[j];
+        // the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
+        const double vj = __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         L.v_lds[j] = vj;
-        if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
+        if (logs) L.lv_lds[j] = log(vj);
     }
     __syncthreads();
     return live;
@@ -719,30 +729,6 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     __syncthreads();
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
-    if (!GBINS && a.fold_tail == 2) {
-        // self-validating row: entry j = {tag | low half, tag | high half} of the double, one 16-byte write-through
-        // store (each 8-byte half is valid on its own, so a torn 16-byte store is harmless); nothing to drain or count
-        if (live) {
-            double2* row16 = reinterpret_cast<double2*>(a.partials) + (size_t)row_id * (n_cols + 1);
-            const unsigned long long tag = (unsigned long long)a.fold_tag << 32;
-            auto put = [&](int j, double s) {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
-                store_pair(row16 + j, __longlong_as_double((long long)(tag | (bits & 0xffffffffull))),
-                           __longlong_as_double((long long)(tag | (bits >> 32))), 2);
-            };
-            for (int j = tid; j < n_cols; j += kBlock) {
-                double s = L.bins[j];
-                for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
-                put(j, s);
-            }
-            if (tid == 0) {
-                double s = L.wsum[0];
-                for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
-                put(n_cols, s);
-            }
-        }
-        return;
-    }
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
     // the row is folded inside THIS launch (not for a cancelled pre-armed launch: nobody will fold, and the arrival
     // counters must stay zero for the next launch)
@@ -919,101 +905,17 @@ __device__ __forceinline__ void fold_role(const SweepArgs& a, int nprod)
     fold_finish(tsum, ok, n1, a.fold_out, a.sync, a.fold_blocks, true, a.host_flag, a.host_seq);
 }
 
-// Tail fold over self-validating rows (SweepArgs::fold_tail == 2).  Same lane -> (row-lane, column) map, same
-// batches and the same summation order as fold_columns, so the result is bit-identical to reduce_partials; the only
-// difference is how a row entry becomes readable: the lane re-reads its two granules (agent-scope loads, which miss
-// the XCD's L2) until both carry this launch's tag.  Bounded by wall-clock time; a lane that gives up poisons the
-// block's outputs with NaN.
-template <int BLOCK>
-__device__ __forceinline__ void fold_role_tagged(const SweepArgs& a, int nprod)
-{
-    extern __shared__ double lds[];
-    double* red = lds;                                   // [BLOCK/64][kReduceCols]
-    constexpr int kRowLanes = BLOCK / kReduceCols;
-    constexpr int kWaves = BLOCK / 64;
-    constexpr int kBatch = 8;
-    const int n1 = a.n + 1;
-    const int c = threadIdx.x % kReduceCols;
-    const int r = threadIdx.x / kReduceCols;
-    const int col = blockIdx.x * kReduceCols + c;
-    const unsigned long long tag = (unsigned long long)a.fold_tag << 32;
-    const unsigned long long hi_mask = 0xffffffff00000000ull;
-    const long long t0 = (long long)wall_clock64();
-    const long long limit = 200000000ll;                 // 2 s of the 100 MHz wall clock
-    bool ok = true;
-    double s = 0.0;
-    if (col < n1) {
-        const unsigned long long* base = reinterpret_cast<const unsigned long long*>(a.partials) + 2 * (size_t)col;
-        const size_t pitch = 2 * (size_t)n1;             // granules per row
-        auto issue = [&](int row, unsigned long long& g0, unsigned long long& g1) {
-            const unsigned long long* g = base + (size_t)row * pitch;
-            g0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        // one batch: up to kBatch rows of this lane, ALL in flight at once; the entries that do not carry the tag yet
-        // are re-read together (a row-by-row wait would pay one memory round trip per row after the last arrival)
-        auto batch = [&](int row0, auto count) {
-            constexpr int CNT = decltype(count)::value;
-            unsigned long long g0[CNT], g1[CNT];
-            for (int b = 0; b < CNT; ++b) issue(row0 + b * kRowLanes, g0[b], g1[b]);
-            for (;;) {
-                bool all = true;
-                for (int b = 0; b < CNT; ++b) all &= ((g0[b] & hi_mask) == tag) & ((g1[b] & hi_mask) == tag);
-                if (all) break;
-                if ((long long)wall_clock64() - t0 > limit) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
-                for (int b = 0; b < CNT; ++b)
-                    if ((g0[b] & hi_mask) != tag || (g1[b] & hi_mask) != tag) issue(row0 + b * kRowLanes, g0[b], g1[b]);
-            }
-            for (int b = 0; b < CNT; ++b)   // ascending rows: the summation order of fold_columns
-                s += __longlong_as_double((long long)((g0[b] & 0xffffffffull) | (g1[b] << 32)));
-        };
-        int row = r;
-        for (; row + (kBatch - 1) * kRowLanes < nprod; row += kBatch * kRowLanes) batch(row, std::integral_constant<int, kBatch>());
-        // the remaining (< kBatch) rows of this lane, still in ascending order: 4 + 2 + 1
-        if (row + 3 * kRowLanes < nprod) { batch(row, std::integral_constant<int, 4>()); row += 4 * kRowLanes; }
-        if (row + kRowLanes < nprod) { batch(row, std::integral_constant<int, 2>()); row += 2 * kRowLanes; }
-        if (row < nprod) batch(row, std::integral_constant<int, 1>());
-    }
-#pragma unroll
-    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* bad = reinterpret_cast<int*>(lds + kWaves * kReduceCols);   // dynamic LDS only: the kernels' LDS ceiling is all dynamic
-    if (threadIdx.x == 0) *bad = 0;
-    __syncthreads();
-    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
-    if (!ok) *bad = 1;
-    __syncthreads();
-    const bool all_ok = *bad == 0;
-    double tsum = 0.0;
-    if (threadIdx.x < kReduceCols) {
-        tsum = red[c];
-        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
-    }
-    fold_finish(tsum, all_ok, n1, a.fold_out, a.sync, a.fold_blocks, false, a.host_flag, a.host_seq);
-}
-
 template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
     if constexpr (!GBINS) {
-        if (!a.fold_tail && (int)blockIdx.x < a.fold_blocks) {
+        if ((int)blockIdx.x < a.fold_blocks) {
             fold_role<BLOCK>(a, (int)gridDim.x - a.fold_blocks);
             return;
         }
     }
-    const int fb = (GBINS || a.fold_tail) ? 0 : a.fold_blocks;
-    const bool live = sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
-    if constexpr (!GBINS) {
-        // tail fold: the first fold_blocks blocks of the grid, done with their own pools, wait for everybody's row
-        // (all blocks of the grid are resident at once -- checked by the host -- so nobody waits for a block that
-        // cannot start) and fold 8 columns each: no second launch, no blocks that only wait
-        if (a.fold_tail && live && (int)blockIdx.x < a.fold_blocks) {
-            __syncthreads();
-            if (a.fold_tail == 2) fold_role_tagged<BLOCK>(a, (int)gridDim.x);
-            else fold_role<BLOCK>(a, (int)gridDim.x);
-        }
-    }
+    const int fb = GBINS ? 0 : a.fold_blocks;
+    (void)sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
 }
 
 // Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
@@ -1022,8 +924,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
-    const bool tail = !GBINS && ma.common.fold_tail != 0;
-    const int fb = (GBINS || tail) ? 0 : ma.common.fold_blocks;
+    const int fb = GBINS ? 0 : ma.common.fold_blocks;
     if (!GBINS && (int)blockIdx.x < fb) {
         fold_role<BLOCK>(ma.common, (int)gridDim.x - fb);
         return;
@@ -1113,11 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         }
         break;
     }
-    if (tail && live && (int)blockIdx.x < ma.common.fold_blocks) {   // tail fold, see sweep_kernel
-        __syncthreads();
-        if (ma.common.fold_tail == 2) fold_role_tagged<BLOCK>(ma.common, (int)gridDim.x);
-        else fold_role<BLOCK>(ma.common, (int)gridDim.x);
-    }
+    (void)live;
 }
 
 // The same fold as its own launch (several sweep launches per evaluation, or "inline_fold" = 0).
@@ -1257,21 +1154,9 @@ hipError_t launch_gather(const int2* chunks, const int* entries, const double* f
 // the command processor at the kernel's first and last wavefront (hipExtLaunchKernel): that is the
 // kernel's own execution span, the quantity rocprofv3 reports, without the ~2.5 us that a
 // hipEventRecord / launch / hipEventRecord bracket adds.
-static thread_local int* t_occupancy = nullptr;   // LaunchCfg::occupancy of the launch being dispatched
-
 template <class K, class... A>
 static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEvent_t e0, hipEvent_t e1, A... args)
 {
-    if (t_occupancy) {   // query only: how many blocks of exactly this kernel / block size / LDS size fit one CU
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), (int)b.x, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            nb = 0;
-        }
-        *t_occupancy = nb;
-        t_occupancy = nullptr;
-        return;
-    }
     if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, (std::uint32_t)lds, s, e0, e1, 0u, args...);
     else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
 }
@@ -1304,8 +1189,7 @@ static hipError_t set_lds_attr(size_t bytes)
 template <int B>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid + ((ma.common.gflow || ma.common.fold_tail) ? 0 : ma.common.fold_blocks)), b(B);
-    t_occupancy = c.occupancy;
+    dim3 g(c.grid + (ma.common.gflow ? 0 : ma.common.fold_blocks)), b(B);
     if (ma.common.gflow) {
         if (mat) launch_k(&sweep_multi<true, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
         else launch_k(&sweep_multi<false, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
@@ -1347,8 +1231,7 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
 template <class Ops, int B>
 static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid + ((a.gflow || a.fold_tail) ? 0 : a.fold_blocks)), b(B);
-    t_occupancy = c.occupancy;
+    dim3 g(c.grid + (a.gflow ? 0 : a.fold_blocks)), b(B);
     hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
     if (a.gflow) { // large-market mode, one pool per lane per tile only
         if (mat) launch_k(&sweep_kernel<Ops, true, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);

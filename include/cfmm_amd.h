@@ -87,9 +87,7 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  * "host_flag" (default 1: a zero-copy host-pointer sweep ends when the last fold block raises a flag in mapped host memory,
  * which the caller polls, instead of on the stream's completion signal), "host_granules" (default 1: such a sweep delivers {psi, acc} as self-validating 8-byte granules that the
  * library re-reads until complete, instead of outputs + flag word; same values), "inline_fold" (default 0; 1 = the partial rows are
- * folded by extra blocks of the sweep launch instead of by a second launch, 2 = by the first blocks of the grid after their
- * own share of the sweep, when the whole grid is resident at once, 3 = as 2 over self-validating rows: 2-5 % faster than
- * the second launch on single-family markets, for a context that has the GPU to itself -- same bits in every form), "multi_threads"
+ * folded by extra blocks of the sweep launch instead of by a second launch -- same bits, measured slower), "multi_threads"
  * (multi-device contexts, see cfmm_ctx_create_multi), "zero_copy" (default 1: host-pointer calls
  * exchange v / Psi through mapped pinned memory instead of copy commands), "fuse_segments" (default 1: all
  * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate

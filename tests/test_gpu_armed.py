@@ -117,18 +117,3 @@ def test_armed_route_stress_never_stalls():
         assert worst < 0.5, f"slowest route took {worst:.3f} s"
     finally:
         be.close()
-
-
-@pytest.mark.parametrize("mode", [2, 3])
-def test_armed_route_with_tail_fold_is_bit_identical(mode):
-    """pre-armed launches whose first blocks also fold the rows (inline_fold = 2): a cancelled launch must leave the
-    arrival counters untouched, or the next launch would fold early"""
-    n = 64
-    batches = [synth.product_pools(60_000, n, seed=3), synth.geomean_pools(40_000, n, seed=4)]
-    c = synth.linear_prices(n, seed=3)
-    a = run_route(batches, n, OBJ_LINEAR_NONNEGATIVE, c, 0, 1, v0=np.ones(n), inline_fold=mode)
-    b = run_route(batches, n, OBJ_LINEAR_NONNEGATIVE, c, 0, 0, v0=np.ones(n), inline_fold=0)
-    assert a[2]["evaluations"] == b[2]["evaluations"]
-    for k in (0, 1, 3, 4):
-        np.testing.assert_array_equal(a[k], b[k])
-    np.testing.assert_array_equal(a[6], a[3])

@@ -27,12 +27,8 @@ def _pair(n, batches, mode=1, **opts):
     return a, b
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3], ids=["extra_blocks", "tail", "tail_tagged_rows"])
 @pytest.mark.parametrize("shape", ["config2", "config3mini", "config4mini", "bounded", "tiny", "n1024"])
-def test_inline_fold_bitwise_equals_separate_fold(shape, mode):
-    """mode 1: extra blocks in front of the grid only fold; mode 2: the first blocks of the grid fold after their own
-    share of the sweep (no extra blocks; the library checks that the whole grid is resident at once); mode 3: the same
-    over self-validating rows (every entry carries the launch's tag: no drain, no arrival counters, no ticket)."""
+def test_inline_fold_bitwise_equals_separate_fold(shape):
     if shape == "config2":
         n, batches = 64, [synth.product_pools(100_000, 64, seed=3)]
     elif shape == "config3mini":
@@ -45,7 +41,7 @@ def test_inline_fold_bitwise_equals_separate_fold(shape, mode):
         n, batches = 2, [synth.product_pools(3, 2, seed=7)]
     else:
         n, batches = 1024, [synth.product_pools(70_000, 1024, seed=8)]
-    a, b = _pair(n, batches, mode)
+    a, b = _pair(n, batches)
     try:
         rng = np.random.default_rng(11)
         for it in range(40):   # back to back: the fold blocks re-read row addresses they read one sweep ago
