@@ -9,6 +9,7 @@
 //   (C) kernel launched earlier; the host writes v and the word straight into DEVICE memory
 //       (fine-grained allocation through the PCIe BAR), all blocks poll that
 //   (D) as (L), but the host has written v into device memory through the BAR before the launch
+//   (E) as (C), but v itself is self-validating ({sequence tag, 32 bits} granules): one round trip instead of two
 // Every wait is bounded by wall-clock time (1 s), so a lost signal cannot hang the GPU.
 // build: hipcc --offload-arch=gfx950 -O3 -o scripts/native/handoff.bin scripts/native/handoff.hip
 #include <hip/hip_runtime.h>
@@ -72,7 +73,24 @@ __global__ __launch_bounds__(256) void eval_k(int mode, const unsigned long long
         v = v_dev;
     }
     double s = 0.0;
-    if (ok) {
+    if (mode == 5) {   // the price vector itself carries the sequence tag: two granules {tag, 32 bits} per double
+        const unsigned long long* g = reinterpret_cast<const unsigned long long*>(v_src);
+        const unsigned long long tag = (seq & 0xffffffffull) << 32;
+        const long long t0 = (long long)wall_clock64();
+        for (int j = tid; j < n; j += 256) {
+            unsigned long long a, b;
+            for (;;) {
+                a = __hip_atomic_load(g + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                b = __hip_atomic_load(g + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((a >> 32 << 32) == tag && (b >> 32 << 32) == tag) break;
+                if ((long long)wall_clock64() - t0 > kTimeoutTicks) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            vs[j] = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) s += vs[j];
+    } else if (ok) {
         for (int j = tid; j < n; j += 256)
             vs[j] = (mode == 2)   ? __hip_atomic_load(v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                     : (mode == 0 || mode == 4) ? v[j]      // a fresh launch: plain loads, as the library's stage_prices does
@@ -160,7 +178,7 @@ int main()
         const double* vsrc = d_hv;
         volatile unsigned long long* host_sig = h_sig;
         double* host_v = h_v;
-        if (mode == 3 || mode == 4) {
+        if (mode == 3 || mode == 4 || mode == 5) {
             sig = (const unsigned long long*)(d_fine + 8192);
             vsrc = (const double*)d_fine;
             host_sig = (volatile unsigned long long*)(d_fine + 8192);
@@ -175,6 +193,17 @@ int main()
                 busy_us(25.0);     // the kernel is resident and polling by now (previous evaluation + host solver time)
             }
             const double t0 = now_us();
+            if (mode == 5) {
+                unsigned long long* hg = reinterpret_cast<unsigned long long*>(host_v);
+                const unsigned long long tag = (seq & 0xffffffffull) << 32;
+                for (int j = 0; j < n; ++j) {
+                    const double x = 1.0 + j + it;
+                    unsigned long long bits;
+                    std::memcpy(&bits, &x, 8);
+                    hg[2 * j] = tag | (bits & 0xffffffffull);
+                    hg[2 * j + 1] = tag | (bits >> 32);
+                }
+            } else
             for (int j = 0; j < n; ++j) host_v[j] = 1.0 + j + it;   // "the solver's new v"
             if (mode == 0 || mode == 4) {
                 __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -202,6 +231,8 @@ int main()
     run(2, "(B) armed, block 0 polls host memory and relays v + word on the device");
     if (bar_ok) run(3, "(C) armed, host writes v + word into device memory (BAR)");
     if (bar_ok) run(4, "(D) launch when v is ready, v written into device memory (BAR)");
+    if (bar_ok) run(5, "(E) armed, host writes v as tagged granules into device memory (BAR), no word");
+    if (bar_ok) run(3, "(C) again");
     run(0, "(L) again");
     return 0;
 }
