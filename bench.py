@@ -570,6 +570,8 @@ def main():
                                  if fused_peer else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
                                 if use_dist else "single GPU, no collective")},
         "roofline": roofline,
+        "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "xcd_map", "nt_stores",
+                                                               "inline_fold", "armed", "host_granules", "host_flag", "zero_copy")},
     }
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check
