@@ -83,7 +83,8 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
 /* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 512 | 1024 threads),
  * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
  * per block, 2 = one per wavefront), "time_kernels", "nt_stores" (trade stores: 0 plain, 1 non-temporal, 2 write-through = default), "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
- * walks only, 1 wavefront-cooperative deep walks), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream),
+ * walks only, 1 wavefront-cooperative deep walks; per-segment launches only -- a fused multi-family launch always runs the
+ * cooperative variant, which computes the same bits), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream),
  * "host_flag" (default 1: a zero-copy host-pointer sweep ends when the last fold block raises a flag in mapped host memory,
  * which the caller polls, instead of on the stream's completion signal), "host_granules" (default 1: such a sweep delivers {psi, acc} as self-validating 8-byte granules that the
  * library re-reads until complete, instead of outputs + flag word; same values), "inline_fold" (default 0; 1 = the partial rows are
