@@ -486,14 +486,14 @@ def main():
             be.ctx.set_option("zero_copy", 1)
             return r
 
-        def eval_block():
-            be.ctx.set_option("spin_wait", 0)
+        def eval_stream_wait():
+            be.ctx.set_option("host_flag", 0)
             r = be.eval(v)
-            be.ctx.set_option("spin_wait", 1)
+            be.ctx.set_option("host_flag", 1)
             return r
 
         for name, fn in (("eval", lambda: be.eval(v)), ("eval_with_copy_commands", eval_copy),
-                         ("eval_blocking_sync", eval_block),
+                         ("eval_stream_wait", eval_stream_wait),
                          ("find_arb", lambda: be.find_arb(v))):
             for _ in range(5):
                 fn()
@@ -566,12 +566,12 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "pools_per_gpu": m_rank, "n_tokens": n,
                    "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
                    "sharding": ((f"pools x{world}, fold + one-shot xGMI peer all-reduce of n_tokens+1 f64 in one launch per step"
-                                 + (" (buffers: library IPC export)" if type(peer).__name__ == "IpcPeers" else " (buffers: torch symmetric memory)")
+                                 + " (buffers: library IPC export)"
                                  if fused_peer else f"pools x{world}, RCCL all-reduce of n_tokens+1 f64 per step")
                                 if use_dist else "single GPU, no collective")},
         "roofline": roofline,
-        "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "xcd_map", "nt_stores",
-                                                               "inline_fold", "armed", "host_granules", "host_flag", "zero_copy")},
+        "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "fast_math", "armed",
+                                                               "stop_in_noise", "host_flag", "zero_copy")},
     }
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check

@@ -54,7 +54,7 @@ class CFMMDeviceError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile libcfmm_amd.so for gfx950 with hipcc (csrc/Makefile)."""
-    srcs = [os.path.join(CSRC, f) for f in ("sweep_kernels.hip", "cfmm_abi.hip", "sweep.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "cfmm_amd.h"))
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -121,15 +121,15 @@ def lib():
     L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
                                        C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
     L.cfmm_set_peers.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64]
-    L.cfmm_peer_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64,
-                                      C.c_uint64, C.c_void_p]
+    L.cfmm_peer_buffer_bytes.argtypes = [C.c_int32]
+    L.cfmm_peer_buffer_bytes.restype = C.c_int64
     L.cfmm_peer_buffer_alloc.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_char_p]
     L.cfmm_peer_buffer_open.argtypes = [_ctx, C.c_char_p, C.POINTER(C.c_uint64)]
     L.cfmm_peer_buffer_close.argtypes = [_ctx, C.c_uint64]
     L.cfmm_peer_buffer_free.argtypes = [_ctx, C.c_uint64]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
-    L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p, _i32p]
+    L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p]
     _lib = L
     return L
 
@@ -362,11 +362,10 @@ class Context:
     def segments(self):
         out = []
         for s in range(self._L.cfmm_segment_count(self._h)):
-            k, b, g, u = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            k, b, g = C.c_int32(), C.c_int32(), C.c_int32()
             m = C.c_int64()
-            self._check(self._L.cfmm_segment_info(self._h, s, C.byref(k), C.byref(m), C.byref(b), C.byref(g),
-                                                  C.byref(u)))
-            out.append({"kind": k.value, "m": m.value, "block": b.value, "grid": g.value, "unroll": u.value})
+            self._check(self._L.cfmm_segment_info(self._h, s, C.byref(k), C.byref(m), C.byref(b), C.byref(g)))
+            out.append({"kind": k.value, "m": m.value, "block": b.value, "grid": g.value})
         return out
 
 

@@ -1,0 +1,148 @@
+// abi_route.cpp -- route!(r) in ONE call (src/router.jl:58-108): the library's own L-BFGS-B (lbfgsb.cpp) drives the
+// device evaluations, with the reference's objectives (src/objectives.jl:51-146), bounds (src/router.jl:67-70) and
+// v-cache rule (:74, :92).  Also the bare solver for host-side callers.
+#include "ctx.h"
+#include "lbfgsb.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+using namespace cfmm;
+
+extern "C" {
+
+int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
+                         cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
+                         int32_t maxiter, int32_t boxed_from_nbd, cfmm_route_info* info)
+{   // (the solver's defaults: reference behaviour, no noise-floor stop)
+    if (n < 1 || !x || !nbd || !fg) return fail(nullptr, CFMM_ERR_INVALID_ARG, "bad argument to cfmm_lbfgsb_minimize");
+    LbfgsbOptions opt;
+    opt.boxed_from_nbd = boxed_from_nbd != 0;
+    opt.m = m;
+    opt.factr = factr;
+    opt.pgtol = pgtol;
+    opt.maxfun = maxfun;
+    opt.maxiter = maxiter;
+    std::vector<int> nb(nbd, nbd + n);
+    LbfgsbResult r = lbfgsb_minimize(n, x, lower, upper, nb.data(),
+                                     [&](const double* xx, double* gg) { return fg(user, xx, gg); }, opt);
+    if (info) {
+        info->f = r.f;
+        info->proj_grad = r.proj_grad;
+        info->iterations = r.iterations;
+        info->evaluations = r.evaluations;
+        info->sweeps = r.evaluations;
+        info->status = r.status;
+        info->sweep_seconds = 0.0;
+        info->total_seconds = 0.0;
+    }
+    return CFMM_OK;
+}
+
+int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec, int32_t objective_index,
+               const double* v0, int32_t m, double factr, double pgtol, int32_t maxfun, int32_t maxiter,
+               double* v_out, double* psi_out, cfmm_route_info* info)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    const int n = c->n;
+    if (!objective_vec) return fail(c, CFMM_ERR_INVALID_ARG, "objective vector is null");
+    if (objective_kind != CFMM_OBJ_LINEAR_NONNEGATIVE && objective_kind != CFMM_OBJ_BASKET_LIQUIDATION)
+        return fail(c, CFMM_ERR_INVALID_ARG, "unknown objective kind %d", objective_kind);
+    const bool linear = objective_kind == CFMM_OBJ_LINEAR_NONNEGATIVE;
+    if (linear) {
+        for (int j = 0; j < n; ++j)
+            if (!(objective_vec[j] > 0.0)) // src/objectives.jl:54
+                return fail(c, CFMM_ERR_INVALID_ARG, "all elements must be strictly positive");
+    } else if (objective_index < 0 || objective_index >= n) {
+        return fail(c, CFMM_ERR_INVALID_ARG, "Invalid index i"); // src/objectives.jl:97
+    }
+    const double* ov = objective_vec;
+    const int oi = objective_index;
+
+    // bounds: src/router.jl:67-70 with lower_limit/upper_limit of src/objectives.jl:78-79, :123-129
+    std::vector<double> lo(n), up(n, INFINITY), v(n), rv(n);
+    std::vector<int> nbd(n, 2);
+    const double sqrt_eps = std::sqrt(2.220446049250313e-16);
+    for (int j = 0; j < n; ++j) lo[j] = linear ? ov[j] + 1e-8 : sqrt_eps;
+    if (!linear) lo[oi] = 1.0 + sqrt_eps;
+    for (int j = 0; j < n; ++j) rv[j] = v0 ? v0[j] : 1.0 / n; // src/router.jl:61-65
+
+    int sweeps = 0, rc_inner = CFMM_OK;
+    double sweep_s = 0.0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool armed = can_arm(c);
+    struct ArmGuard {   // whatever path leaves this function: no launch stays behind waiting for a price vector
+        cfmm_ctx* c;
+        ~ArmGuard() { armed_cancel(c); }
+    } arm_guard{c};
+    auto timed_sweep = [&](const double* x, bool mat) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (mat) armed_cancel(c);
+        const int rc = (armed && !mat) ? armed_eval(c, x) : host_sweep(c, x, mat);
+        sweep_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++sweeps;
+        return rc;
+    };
+    auto sweep = [&](const double* x) { // fused evaluation: Ψ and acc into c->last_out
+        rc_inner = timed_sweep(x, false);
+        return rc_inner == CFMM_OK;
+    };
+    // f(objective, v) and grad!(G, objective, v): src/objectives.jl:62-76, :106-121
+    auto obj_f = [&](const double* x) -> double {
+        if (linear) {
+            for (int j = 0; j < n; ++j)
+                if (!(ov[j] <= x[j])) return INFINITY;
+            return 0.0;
+        }
+        if (!(x[oi] >= 1.0)) return INFINITY;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += (j == oi) ? 0.0 : ov[j] * x[j];
+        return s;
+    };
+    auto fg = [&](const double* x, double* G) -> double {
+        bool same = true; // src/router.jl:74 / :92: one sweep per evaluation
+        for (int j = 0; j < n && same; ++j) same = x[j] == rv[j];
+        if (!same) {
+            if (!sweep(x)) return NAN;
+            std::copy(x, x + n, rv.begin());
+        }
+        const double fo = obj_f(x);
+        const bool feasible = std::isfinite(fo);
+        for (int j = 0; j < n; ++j) {
+            const double gobj = !feasible ? INFINITY : (linear ? 0.0 : (j == oi ? 0.0 : ov[j]));
+            G[j] = gobj + c->last_out[(size_t)j]; // src/router.jl:96-100
+        }
+        return fo + c->last_out[(size_t)n];        // src/router.jl:85
+    };
+
+    if (!sweep(rv.data())) return rc_inner; // src/router.jl:104
+    std::copy(rv.begin(), rv.end(), v.begin());
+    LbfgsbOptions opt;
+    opt.m = m;
+    opt.factr = factr;
+    opt.pgtol = pgtol;
+    opt.maxfun = maxfun;
+    opt.maxiter = maxiter;
+    opt.boxed_from_nbd = true; // bounds[1,:] .= 2 with an infinite upper limit: the Fortran's "boxed" path
+    opt.stop_in_noise = c->opt_stop_in_noise != 0;   // default off: the stopping rules of L-BFGS-B 3.0, nothing else
+    LbfgsbResult r = lbfgsb_minimize(n, v.data(), lo.data(), up.data(), nbd.data(), fg, opt); // :105
+    if (rc_inner != CFMM_OK) return rc_inner;
+    int rc = timed_sweep(v.data(), true); // src/router.jl:106-107: r.v = v*, find_arb!(r, v*)
+    if (rc != CFMM_OK) return rc;
+    if (v_out) std::copy(v.begin(), v.end(), v_out);
+    if (psi_out) std::memcpy(psi_out, c->last_out.data(), (size_t)n * sizeof(double));
+    if (info) {
+        info->f = r.f;
+        info->proj_grad = r.proj_grad;
+        info->iterations = r.iterations;
+        info->evaluations = r.evaluations;
+        info->sweeps = sweeps;
+        info->status = r.status;
+        info->sweep_seconds = sweep_s;
+        info->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return CFMM_OK;
+}
+
+} // extern "C"

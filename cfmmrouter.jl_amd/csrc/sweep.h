@@ -1,4 +1,4 @@
-// sweep.h -- internal C++ interface between the C ABI (cfmm_abi.hip) and the gfx950 kernels
+// sweep.h -- internal C++ interface between the C ABI (abi_*.cpp) and the gfx950 kernels
 // (sweep_kernels.hip).  Not installed; the public surface is include/cfmm_amd.h.
 #pragma once
 
@@ -7,12 +7,12 @@
 
 namespace cfmm {
 
-constexpr int kSmallBlock = 256;     // 4 wavefronts: small markets, many blocks
-constexpr int kMidBlock = 512;       // 8 wavefronts: fused multi-family launches (finer P/G interleave per CU)
+constexpr int kMidBlock = 512;       // 8 wavefronts: small markets (one tile per block) and fused multi-family launches
 constexpr int kBigBlock = 1024;      // 16 wavefronts: single-family launches, few partial rows
-constexpr int kResidentThreads = 2048 * 256; // grid cap for the fat blocks: one machine of resident threads
-constexpr int kReduceCols = 8;       // tokens per reduce block (one 64 B line of each partial row)
-constexpr int kMaxLdsTokens = 8192;  // up to here v + one bin copy fit the 160 KiB LDS of a CU;
+constexpr int kFoldBlock = 512;      // reduce_partials / reduce_gather
+constexpr int kResidentThreads = 2048 * 256; // one machine of resident threads (256 CUs x 2048)
+constexpr int kReduceCols = 8;       // tokens per fold block (one 64 B line of each partial row)
+constexpr int kMaxLdsTokens = 8192;  // up to here the prices + one bin copy fit the 160 KiB LDS of a CU;
                                      // larger markets pull Ψ per token (sweep_body<..., GBINS=true>)
 constexpr int kGatherChunk = 512;    // incidence entries per wavefront in gather_chunks
 
@@ -25,6 +25,11 @@ struct PackedFeeTok {
     uint32_t gidx;
 };
 constexpr int kMaxFeeTable = 256;
+
+// Window of the "fast" arithmetic (sweep_kernels.hip, div_by / fast_sqrt): when every reserve, fee, liquidity and
+// price of a launch lies in [2^-kFastExp, 2^kFastExp], the IEEE division / square-root sequences run without their
+// range scaffolding (v_div_scale, v_div_fmas, v_div_fixup, ldexp pairs) and still return the correctly rounded bits.
+constexpr int kFastExp = 150;
 
 struct ProductPools {            // src/cfmms.jl:101-111
     const double2* R;            // [m] {R1, R2}
@@ -72,6 +77,8 @@ struct SweepArgs {
     const double* gtab;          // the launch's fee table (device), staged in LDS when gtab_n > 0
     int gtab_n;
     int copies;                  // private bin copies per block (1 or one per wavefront)
+    int fast_ok;                 // 1: every pool constant of the segment lies in the kFastExp window (checked at upload)
+                                 //    and the option "fast_math" is on; the blocks still check the prices they stage
     int64_t m;                   // pools in this segment
     // Trade buffers of the segment (null when !materialize).  compact == 0: Delta[i] = {Δ₁, Δ₂}, Lambda[i] = {Λ₁, Λ₂}
     // (32 B written per pool).  compact == 1: at most one direction of a pool trades, so ONE 16-byte record goes
@@ -86,19 +93,8 @@ struct SweepArgs {
     int compact;
     double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
-    int nt_stores;               // trade stores: 0 plain, 1 non-temporal, 2 write-through
     int reverse;                 // 1: every lane walks its tiles last-to-first (alternates between consecutive sweeps, so a
                                  //    sweep starts on the pool data the previous one left in the XCD's L2)
-    // In-launch row fold (fold_blocks > 0): the first fold_blocks blocks of the grid do not sweep;
-    // they wait until every sweeping block has published its partial row (write-through stores +
-    // arrival counters, no release fence) and then fold the rows into fold_out -- the work of
-    // reduce_partials without a second launch.  sync = kSyncWords zero-initialised uint32 words,
-    // left zero again by the launch.
-    int fold_blocks;
-    unsigned* sync;
-    double* fold_out;            // [n+1] {Ψ, acc}
-    unsigned long long* host_flag; // optional (mapped pinned host memory): set to host_seq by the last fold block
-    unsigned long long host_seq;   // once every fold block's part of fold_out has been written through to it
     // Pre-armed launch (arm_word != null; cfmm_route): the kernel is enqueued BEFORE its price vector exists and every
     // block, after issuing its first pool loads and clearing its bins, waits until the host has written v into `v`
     // (fine-grained device memory, through the PCIe BAR) and then arm_seq into *arm_word -- the launch latency is
@@ -110,11 +106,6 @@ struct SweepArgs {
     long long arm_timeout;
 };
 constexpr unsigned long long kArmCancel = 1ull << 63;
-constexpr unsigned long long kHostGranules = 1ull << 63;   // SweepArgs::host_seq / launch_reduce: outputs as tagged granules (fold_finish)
-constexpr int kArriveShards = 16;    // arrival counters (one 128-B line each): block b arrives on shard b % 16
-constexpr int kSyncStride = 32;      // uint32 words per shard line
-constexpr int kSyncWords = (kArriveShards + 1) * kSyncStride;   // + the fold blocks' own "done" ticket line
-constexpr int kMaxFoldTokens = 1024; // above this the fold stays a separate launch (too many fold blocks)
 
 // One launch over up to kMaxMulti segments (sweep_multi).
 constexpr int kMaxMulti = 4;
@@ -125,6 +116,7 @@ union AnyPools {
 };
 struct MultiSeg {
     int kind;
+    int fast_ok;                 // see SweepArgs::fast_ok
     int64_t m;
     AnyPools pools;
     double2* Delta;
@@ -136,20 +128,18 @@ struct MultiArgs {
     int nseg;
     int xcd_map;                 // 1: XCD-aware, cost-weighted block -> segment map (needs grid % 256 == 0): deal j = b / 8
                                  //    (the 8 blocks that land on the 8 XCDs together) belongs to segment
-                                 //    pattern[(j + j / 32) % 32] and is that segment's deal number (j / 32)·w + rank[...]
+                                 //    pattern[(j + j / 32) % 32] and is that segment's deal number (j / 32)·w + rank[...];
+                                 // 0: block b -> segment b % nseg (grids that are no multiple of 256 blocks: small markets)
     unsigned char pattern[32];   // segment of each of 32 consecutive deals; segment s appears seg_w[s] times
     unsigned char rank[32];      // rank[p] = #{p' < p : pattern[p'] == pattern[p]}
     int seg_w[kMaxMulti];        // deals out of 32 given to each segment (in proportion to pools x cost per pool)
-    int wave_split;              // 1: every block sweeps every segment, its wavefronts dealt to the families
-                                 //    (needs (block / 64) % nseg == 0)
     MultiSeg seg[kMaxMulti];
-    SweepArgs common;            // v, n, n_pad, copies, partials (row 0 of this launch), nt_stores
+    SweepArgs common;            // v, n, n_pad, copies, partials (row 0 of this launch)
 };
 
 struct LaunchCfg {
-    int block;                   // kSmallBlock, kMidBlock or kBigBlock
+    int block;                   // kMidBlock or kBigBlock
     int grid;
-    int unroll;                  // 1, 2 or 4 pools per lane per tile
     size_t lds_bytes;
     hipEvent_t ev_start = nullptr; // both set: the launch is timed by the command processor
     hipEvent_t ev_stop = nullptr;  // (hipExtLaunchKernel), i.e. the kernel's own execution span
@@ -162,7 +152,8 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool materialize,
                         hipStream_t s);
 
-// grid must be a multiple of ma.nseg; block b writes partial row b (see sweep_multi for the block -> segment map).
+// block b writes partial row b (see sweep_multi for the block -> segment map); without xcd_map the grid must be a
+// multiple of ma.nseg.
 hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool materialize, hipStream_t s);
 
 // Large markets: chunk_sums[c] = sum of flow[entries[chunks[c].x .. chunks[c].y)], then
@@ -171,24 +162,27 @@ hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool materializ
 hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
                          const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s);
 
-// out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
-// `block` = the block size of the sweep launches that produced the rows (same summation order as the in-launch fold).
-// host_flag != null (needs sync): out is mapped host memory; the last fold block sets *host_flag = host_seq after
-// every block's part of out has been written through.
+// How a fold launch hands {Ψ, acc} to the host (mapped pinned memory), if at all: gran != null -> the block's 8 columns
+// leave as 16 SELF-VALIDATING 8-byte granules {tag, 32 bits of the double} (two per column) written by one store
+// instruction = two full 64-byte lines; the host re-reads them until all carry the tag -- no drain of the output stores,
+// no ticket, no flag word.  gran == null: plain stores to `out` (device consumers).
+struct HostOut {
+    unsigned long long* gran;    // [2 * ceil8(n1)] words in mapped host memory, or null
+    unsigned long long tag;      // 1 .. 2^32 - 1 (0 = an empty buffer)
+};
 struct ArmWord {                 // see SweepArgs::arm_word; {nullptr, 0} = not armed
     const unsigned long long* word;
     unsigned long long seq;
 };
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
-                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, unsigned* sync = nullptr,
-                         unsigned long long* host_flag = nullptr, unsigned long long host_seq = 0,
+// out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, HostOut host = HostOut{nullptr, 0},
                          ArmWord arm = ArmWord{nullptr, 0});
 
 // Sharded runs (cfmm_set_peers): the row fold fused with the one-shot all-reduce over xGMI peer
 // mappings (reduce_gather in sweep_kernels.hip): block b folds its kReduceCols columns, publishes
 // them as self-validating granules in this rank's symmetric buffer and adds the same columns of
-// every peer in rank order -- one launch instead of reduce_partials + cfmm_peer_allreduce, one hop
-// on the critical path, no hand-off between the blocks of a rank.
+// every peer in rank order -- one launch, one hop on the critical path, no hand-off between the blocks of a rank.
 constexpr int kMaxPeers = 16;
 struct PeerSet {
     unsigned long long* gran[kMaxPeers];    // peer p's granules: [2][count][2] uint64 (see include/cfmm_amd.h)
@@ -196,17 +190,18 @@ struct PeerSet {
     long long count;                        // n_tokens + 1
     unsigned long long seq;                 // 1, 2, ... identical on every rank
     long long timeout_ticks;                // wall_clock64() ticks (100 MHz) before a wait gives up (NaN output)
-    unsigned* sync;                         // the context's ticket words (fold_finish), for the host flag
-    unsigned long long* host_flag;          // optional: raised (= host_seq) once all of `out` (mapped host memory) is written
-    unsigned long long host_seq;
+    HostOut host;                           // optional: the global {Ψ, acc} also travel to the host as granules
+    ArmWord arm;                            // pre-armed evaluation: a cancelled launch publishes nothing
 };
-hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s,
                                 const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
-// R <- (R + gamma*Delta) - Lambda in place; GeometricMean (Q, eta non-null): Q <- the exponents' constants for the new R
+// R <- (R + gamma*Delta) - Lambda in place; GeometricMean (Q, eta non-null): Q <- the exponents' constants for the new R;
+// *left_window <- 1 if a new reserve lies outside [2^-kFastExp, 2^kFastExp]
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, hipStream_t s);
-// compact trade records -> full {Δ₁, Δ₂} / {Λ₁, Λ₂} arrays (cfmm_trades_dev)
+                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, int* left_window,
+                                  hipStream_t s);
+// compact trade records -> full {Δ₁, Δ₂} / {Λ₁, Λ₂} arrays (cfmm_trades_dev, cfmm_get_trades*)
 hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const double2* ovB, double2* Delta, double2* Lambda,
                                 int64_t m, hipStream_t s);
 

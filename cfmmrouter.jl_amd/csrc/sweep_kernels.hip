@@ -13,8 +13,8 @@
 // Mapping to the machine.  A two-coin closed form is ~25 dependent flops with no parallelism
 // inside a pool, so the unit of work is ONE LANE PER POOL (64 pools per wavefront); the
 // data-parallel axis is the pool index, exactly the axis the reference threads over.  Pool
-// state is stored as three coalesced streams (reserve pairs 16 B, fee 8 B, token-index pair
-// 8 B per lane) and trades leave as two 16 B/lane streams.  Each wavefront owns a private
+// state is stored as coalesced streams (reserve pairs 16 B + a packed {tokens, fee index} record 8 B per
+// lane) and trades leave as one 16 B/lane stream.  Each wavefront owns a private
 // copy of the n_tokens netflow bins in LDS and scatters (Lambda - Delta) into it with
 // ds_add_f64; the block then folds its copies in a fixed order and writes one partial row to
 // global memory.  A second tiny kernel folds the rows, again in a fixed order, so a sweep
@@ -47,8 +47,86 @@ __device__ __forceinline__ double max0(double x)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded binary64 division and square root without the range scaffolding
+// ---------------------------------------------------------------------------------------------
+// For a / b the compiler emits   d = v_div_scale(b, b, a);  y = v_rcp(d);  two Newton steps on y (4 fma);
+// n = v_div_scale(a, b, a);  q = n·y;  r = fma(−d, q, n);  v_div_fmas(r, y, q);  v_div_fixup     (11 instructions),
+// and for sqrt(x) a compare / select / ldexp pair around   y = v_rsq(x);  s = x·y;  h = y/2;  two coupled Newton steps
+// (7 fma)   plus a class test                                                                        (16 instructions).
+// The scaffolding only acts outside a huge exponent range: for finite, normal operands with |exponent| <= 300 or so
+// v_div_scale returns its input, v_div_fmas is a plain fma, v_div_fixup returns its first operand and the ldexp pair
+// scales by 2^0.  The SAME core sequences without it therefore return the SAME correctly rounded bits whenever every
+// operand is inside [2^-kFastExp, 2^kFastExp] -- pool constants are checked at upload, the prices by every block while
+// it stages them (`FAST` below); anything else takes the compiler's sequences.  What this buys beyond the 3 + 7
+// instructions: the refined reciprocal y depends on the DIVISOR only, so it is computed once per token (prices) and
+// once per fee tier while they are staged in LDS, and a division by a price or by a fee costs three instructions.
+// (tests/test_gpu_parity.py: every ProductTwoCoin / UniV3 trade bit-equal to the CPU restatement with fast_math on and
+// off; tests/native/fastmath_check.hip: 2^30 random operands against the compiler's / and sqrt.)
+__device__ __forceinline__ double rcp_refined(double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// a / b given yb = rcp_refined(b);  a finite (any sign, zero included: a = ±0 returns a·yb = ±0 like IEEE for b > 0 --
+// the residual fma then adds +0 to −0, so the sign of a zero quotient is restored explicitly)
+__device__ __forceinline__ double div_by(double a, double b, double yb)
+{
+    const double q = a * yb;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, yb, q);
+}
+__device__ __forceinline__ double div_by_signed_zero(double a, double b, double yb)
+{
+    const double q = div_by(a, b, yb);
+    return a == 0.0 ? a : q;      // b > 0 everywhere this is used: ±0 / b = ±0
+}
+__device__ __forceinline__ double fast_div(double a, double b) { return div_by(a, b, rcp_refined(b)); }
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, s, 0.5);
+    s = __builtin_fma(s, r, s);
+    double d = __builtin_fma(-s, s, x);
+    h = __builtin_fma(h, r, h);
+    s = __builtin_fma(d, h, s);
+    d = __builtin_fma(-s, s, x);
+    return __builtin_fma(d, h, s);
+}
+// |x| in [2^-kFastExp, 2^kFastExp] (false for NaN, infinities, zero, denormals)
+__device__ __forceinline__ bool in_fast_window(double x)
+{
+    const int e = (__double2hiint(x) >> 20) & 0x7ff;
+    return e >= 1023 - kFastExp && e <= 1023 + kFastExp;
+}
+
+// Keeps a freshly loaded value in registers at this point of the program.  (Without it the compiler defers the second
+// half of a {γ, rcp(γ)} table read into the branch that uses it by SELECTING BETWEEN POINTERS -- the LDS entry or a
+// stack slot holding the 0.0 of the unpacked path -- and reads it back with a flat load: scratch traffic per tile.)
+__device__ __forceinline__ double pinned(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Prices of a pool's two tokens as the sweep hands them to solve(): the values, their refined reciprocals (FAST only;
+// staged per token in LDS), the fee's refined reciprocal (FAST only: from the LDS fee table, or computed per pool) and
+// log v2 − log v1 (log-space GeometricMean only).
+struct Px {
+    double v1, v2, y1, y2, yg, dlv;
+};
+
+// ---------------------------------------------------------------------------------------------
 // ProductTwoCoin -- src/cfmms.jl:125-140
 // ---------------------------------------------------------------------------------------------
+// Every Ops::load() only ISSUES loads (no arithmetic on what it loaded): the compiler then keeps all of a tile's loads
+// in flight together.  (Round 2 unpacked the {tokens, fee index} record inside load(); the compiler answered with
+// s_waitcnt vmcnt(0) BEFORE it issued the reserve load -- two dependent memory round trips per tile.)  The record is
+// taken apart in resolve(), after the tile's data has arrived.
 
 struct ProductOps {
     static constexpr bool kWaveCooperative = false;
@@ -56,22 +134,35 @@ struct ProductOps {
     struct Raw {
         double2 R;
         double g;
-        int2 ai;
+        int2 ai;      // packed: {tok, gidx} until resolve()
+        double yg;    // refined reciprocal of the fee (FAST with a fee table)
     };
     ProductPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        if (p.pk) {   // packed record: the fee arrives as a table index (carried in g's bits until resolve())
+        Raw r;
+        r.R = p.R[i];
+        r.yg = 0.0;
+        if (p.pk) {
             const PackedFeeTok k = p.pk[i];
-            return Raw{p.R[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx)),
-                       make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16))};
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
+            r.g = 0.0;
+        } else {
+            r.g = p.gamma[i];
+            r.ai = p.Ai[i];
         }
-        return Raw{p.R[i], p.gamma[i], p.Ai[i]};
+        return r;
     }
-    // after stage_prices(): look the fee up in the LDS table
-    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    // after stage_prices(): take the packed record apart and look the fee up in the LDS table {γ, rcp_refined(γ)}
+    __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) r.g = gtab_lds[__double_as_longlong(r.g)];
+        if (p.pk) {
+            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+            const unsigned tok = (unsigned)r.ai.x;
+            r.g = gy.x;
+            r.yg = pinned(gy.y);
+            r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
+        }
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // All four closed forms exactly as written in the reference (:134-138).
@@ -93,9 +184,10 @@ struct ProductOps {
     // the selected operands, hence bit-identical values.  The predicates carry a 1e-12 relative
     // margin (>> the 1e-16 rounding of the forms), so a direction is only skipped where the
     // reference's max(·, 0) provably clamps to 0; the (measure-zero) overlap runs the full forms.
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    template <bool FAST>
+    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
     {
-        const double R1 = r.R.x, R2 = r.R.y, g = r.g;
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g, v1 = px.v1, v2 = px.v2;
         constexpr double kMargin = 1.0 + 1e-12;
         const double a = v1 * R1, b = v2 * R2;
         const bool p1 = (g * b) * kMargin >= a;    // direction 1 possibly active
@@ -103,10 +195,18 @@ struct ProductOps {
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
         if (p1 != p2) {
             const double k = R1 * R2;                          // :132
-            const double gm = g * ((p1 ? v2 : v1) / (p1 ? v1 : v2));   // γ*m, m = v_out / v_in
             const double r_in = p1 ? R1 : R2, r_out = p1 ? R2 : R1;
-            const double d = max0(sqrt(gm * k) - r_in) / g;    // :125
-            const double l = max0(r_out - sqrt(k / gm));       // :126
+            double d, l;
+            if constexpr (FAST) {
+                // m = v_out / v_in through the divisor's staged reciprocal; operands inside the window: same bits
+                const double gm = g * div_by(p1 ? v2 : v1, p1 ? v1 : v2, p1 ? px.y1 : px.y2);
+                d = div_by(__builtin_fmax(fast_sqrt(gm * k) - r_in, 0.0), g, px.yg);   // :125 (finite: max0 == fmax)
+                l = __builtin_fmax(r_out - fast_sqrt(fast_div(k, gm)), 0.0);           // :126
+            } else {
+                const double gm = g * ((p1 ? v2 : v1) / (p1 ? v1 : v2));   // γ*m, m = v_out / v_in
+                d = max0(sqrt(gm * k) - r_in) / g;             // :125
+                l = max0(r_out - sqrt(k / gm));                // :126
+            }
             t.d1 = p1 ? d : 0.0;
             t.d2 = p1 ? 0.0 : d;
             t.l1 = p1 ? 0.0 : l;
@@ -140,16 +240,19 @@ struct GeoMeanOps {
         double2 R, w;
         double g;
         int2 ai;
+        double yg;    // unused (interface of process_pool)
     };
     GeoMeanPools p;
-    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i]}; }
-    __device__ __forceinline__ void resolve(Raw&, const double*) const {}
+    __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i], 0.0}; }
+    __device__ __forceinline__ void resolve(Raw&, const double2*) const {}
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // Same idea as ProductOps::solve: Δ₁,Λ₂ > 0 ⇔ γ·m₁₂·η·R₂ > R₁ and Δ₂,Λ₁ > 0 ⇔ γ·m₂₁·R₁/η > R₂
     // (the bases of :180 exceed r2^(η+1)); only the live direction's two forms (4 pow instead of
     // 8) are evaluated, with the reference's expressions on the selected operands.
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    template <bool FAST>   // (no fast variant: pow dominates and the forms keep the reference's operation order)
+    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
     {
+        const double v1 = px.v1, v2 = px.v2;
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double eta = r.w.x / r.w.y;        // :188
         const double ieta = 1.0 / eta;
@@ -187,7 +290,7 @@ struct GeoMeanOps {
 //     direction 1 (e = η):    exponent = (Q1 + Δ) / (η+1),       Q1 = log γ + log η + log R2 + η·log R1
 //     direction 2 (e = 1/η):  exponent = (Q2 − η·Δ) / (η+1),     Q2 = η·(log γ + log R1 − log η) + log R2
 // with Δ = log v2 − log v1.  Per trading pool that leaves 1 exp + 3 divisions (the exponent, Y and
-// the final /γ) instead of 4 pow + 6 divisions (round 1: 1 log + 2 exp + 3 div); pools inside the
+// the final /γ) instead of 4 pow + 6 divisions; pools inside the
 // no-arbitrage band cost four multiplies and two compares.  The exponent carries an absolute rounding
 // error of a few 1e-16·max(1, η·|l|)/(η+1), so trades agree with the reference-order forms to ~1e-15 of
 // the reserve scale (asserted at 1e-12 in tests/test_gpu_parity.py); unlike r2^η in the reference,
@@ -198,26 +301,42 @@ struct GeoMeanLogOps {
     struct Raw {
         double2 R, Q;
         double eta, g;
-        int2 ai;
+        int2 ai;      // packed: {tok, gidx} until resolve()
+        double yg;
     };
     GeoMeanPools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
+        Raw r;
+        r.R = p.R[i];
+        r.Q = p.Q[i];
+        r.eta = p.eta[i];
+        r.yg = 0.0;
         if (p.pk) {
             const PackedFeeTok k = p.pk[i];
-            return Raw{p.R[i], p.Q[i], p.eta[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx)),
-                       make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16))};
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
+            r.g = 0.0;
+        } else {
+            r.g = p.gamma[i];
+            r.ai = p.Ai[i];
         }
-        return Raw{p.R[i], p.Q[i], p.eta[i], p.gamma[i], p.Ai[i]};
+        return r;
     }
-    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) r.g = gtab_lds[__double_as_longlong(r.g)];
+        if (p.pk) {
+            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+            const unsigned tok = (unsigned)r.ai.x;
+            r.g = gy.x;
+            r.yg = pinned(gy.y);
+            r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
+        }
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
-    // dlv = log v2 − log v1
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, double dlv, Trade& t) const
+    template <bool FAST>
+    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
     {
+        const double v1 = px.v1, v2 = px.v2, dlv = px.dlv;   // dlv = log v2 − log v1
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double eta = r.eta;                     // η = w₁/w₂, prepared at upload
         const double n1 = ((g * v2) * eta) * R2, d1 = v1;   // c₁ = n1/d1: direction 1 trades iff c₁ > R₁
@@ -234,9 +353,16 @@ struct GeoMeanLogOps {
             if (pass == 0 ? !(p1 || p2) : !(p1 && p2)) break;
             const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
             const double A = dir1 ? (r.Q.x + dlv) : (r.Q.y - eta * dlv);
-            const double X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
-            const double Y = ((X * ra) * (dir1 ? d1 : d2)) / (dir1 ? n1 : n2);   // X·r_a/c, c = n/d
-            const double d = max0(X - rb) / g;
+            double X, Y, d;
+            if constexpr (FAST) {   // same correctly rounded quotients for operands inside the window (checked at upload / staging)
+                X = exp(fast_div(A, eta + 1.0));
+                Y = fast_div((X * ra) * (dir1 ? d1 : d2), dir1 ? n1 : n2);
+                d = div_by(max0(X - rb), g, px.yg);
+            } else {
+                X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
+                Y = ((X * ra) * (dir1 ? d1 : d2)) / (dir1 ? n1 : n2);   // X·r_a/c, c = n/d
+                d = max0(X - rb) / g;
+            }
             const double l = max0(ra - Y);
             if (dir1) { t.d1 = d; t.l2 = l; }
             else { t.d2 = d; t.l1 = l; }
@@ -248,7 +374,7 @@ struct GeoMeanLogOps {
 // UniV3 / BoundedProduct -- src/cfmms.jl:294-395 (lane per pool, serial tick walk)
 // ---------------------------------------------------------------------------------------------
 // Everything compute_at_tick (:294-313) derives is independent of v, so it is evaluated ONCE at
-// upload (cfmm_abi.hip, same IEEE operations, hence the same bits) into the constants
+// upload (abi_upload.cpp, same IEEE operations, hence the same bits) into the constants
 // find_arb_pos (:321-337) actually uses:
 //   * the CURRENT tick, visited first by both walks, as one record per pool
 //       cur_a = {k, sA = R₁+α}   cur_b = {sB = R₂+β, δmax↑ = k/β − sA}   cur_c = δmax↓ = k/α − sB
@@ -263,34 +389,51 @@ struct UniV3Ops {
     static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = false;
     struct Raw {
-        double2 pg, ca, cb;
+        double2 pg, ca, cb;   // pg = {current_price, γ}
         double cc;
-        int2 ai;
+        int2 ai;              // packed: {tok, gidx} until resolve()
         int4 walk;
         int64_t i;
+        double yg;
     };
     UniV3Pools p;
     __device__ __forceinline__ Raw load(int64_t i) const
     {
-        const int4 walk = p.has_walk ? p.walk[i] : make_int4(0, 0, 0, 0);
+        Raw r;
+        r.ca = p.cur_a[i];
+        r.cb = p.cur_b[i];
+        r.cc = p.cur_c[i];
+        r.walk = p.has_walk ? p.walk[i] : make_int4(0, 0, 0, 0);
+        r.i = i;
+        r.yg = 0.0;
         if (p.pk) {   // packed record: price alone + {tokens, fee-table index}
             const PackedFeeTok k = p.pk[i];
-            return Raw{make_double2(p.cp[i], __longlong_as_double((long long)(p.gbase + (int)k.gidx))), p.cur_a[i], p.cur_b[i],
-                       p.cur_c[i], make_int2((int)(k.tok & 0xffffu), (int)(k.tok >> 16)), walk, i};
+            r.pg = make_double2(p.cp[i], 0.0);
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
+        } else {
+            r.pg = p.pg[i];
+            r.ai = p.Ai[i];
         }
-        return Raw{p.pg[i], p.cur_a[i], p.cur_b[i], p.cur_c[i], p.Ai[i], walk, i};
+        return r;
     }
-    __device__ __forceinline__ void resolve(Raw& r, const double* gtab_lds) const
+    __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) r.pg.y = gtab_lds[__double_as_longlong(r.pg.y)];
+        if (p.pk) {
+            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+            const unsigned tok = (unsigned)r.ai.x;
+            r.pg.y = gy.x;
+            r.yg = pinned(gy.y);
+            r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
+        }
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
 
-    // find_arb_pos (:321-337) on one prepared walk-list entry
-    __device__ __forceinline__ void list_tick(int e, double price, double& d, double& l) const
+    // find_arb_pos (:321-337) on one prepared walk-list entry; yp = rcp_refined(price) (FAST)
+    template <bool FAST>
+    __device__ __forceinline__ void list_tick(int e, double price, double yp, double& d, double& l) const
     {
         const double2 ks = p.ks[e];
-        const double dd = sqrt(ks.x / price) - ks.y;               // :323
+        const double dd = (FAST ? fast_sqrt(div_by(ks.x, price, yp)) : sqrt(ks.x / price)) - ks.y;   // :323
         d = 0.0;
         l = 0.0;                                                   // :325-327
         if (dd > 0) {
@@ -299,51 +442,77 @@ struct UniV3Ops {
                 d = dt.x;
                 l = p.rout[e];
             } else {
-                l = dt.y - sqrt(price * ks.x);                     // :334
+                l = dt.y - (FAST ? fast_sqrt(price * ks.x) : sqrt(price * ks.x));   // :334
                 d = dd;
             }
         }
     }
 
-    // Lane-per-pool walk (segments whose walk lists are short, e.g. every BoundedProduct pool).
-    __device__ __forceinline__ void solve(const Raw& r, double v1, double v2, Trade& t) const
+    // The part of find_arb! before the walk lists (:340-361 / :381 and the current tick): block-uniformly FAST or not.
+    // Returns false when the pool does not trade (or the price is NaN: t is then all-NaN).
+    template <bool FAST>
+    __device__ __forceinline__ bool head(const Raw& r, const Px& px, Trade& t, bool& up, double& g, double& yg, double& price,
+                                         double& yp, double& sd, double& sl) const
     {
-        const double cp = r.pg.x, g = r.pg.y;
-        const double pr = v1 / v2;                                     // :340
+        const double cp = r.pg.x;
+        g = r.pg.y;
+        yg = FAST ? (p.pk ? r.yg : rcp_refined(g)) : 0.0;
+        const double pr = FAST ? div_by(px.v1, px.v2, px.y2) : px.v1 / px.v2;   // :340
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        if (pr != pr) { t.d1 = t.d2 = t.l1 = t.l2 = pr; return; }      // NaN prices propagate instead of "no trade"
-        if (g * cp <= pr && pr <= cp / g) return;                      // :347-349
-        const bool up = pr < g * cp;                                   // :351
-        const double price = up ? pr / g : 1.0 / (g * pr);             // :361 / :381
-        double sd = 0.0, sl = 0.0;
+        sd = sl = 0.0;
+        up = false;
+        price = 1.0;
+        yp = 1.0;
+        if (pr != pr) { t.d1 = t.d2 = t.l1 = t.l2 = pr; return false; }   // NaN prices propagate instead of "no trade"
+        if (g * cp <= pr && pr <= (FAST ? div_by(cp, g, yg) : cp / g)) return false;   // :347-349
+        up = pr < g * cp;                                                  // :351
+        if constexpr (FAST) price = up ? div_by(pr, g, yg) : fast_div(1.0, g * pr);
+        else price = up ? pr / g : 1.0 / (g * pr);                         // :361 / :381
+        if constexpr (FAST) yp = rcp_refined(price);
         // current tick: `initial` is true here unless the tick is empty (:355-358), so no break test
         const double k0 = r.ca.x;
         if (k0 != 0) {
             const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
             const double dmax = up ? r.cb.y : r.cc;
-            const double dd = sqrt(k0 / price) - s_in;                 // :323
-            if (dd > 0) {                                              // :325-327
-                if (dd >= dmax) {                                      // :330-332
+            const double dd = (FAST ? fast_sqrt(div_by(k0, price, yp)) : sqrt(k0 / price)) - s_in;   // :323
+            if (dd > 0) {                                                  // :325-327
+                if (dd >= dmax) {                                          // :330-332
                     const double2 R = p.curR[r.i];
                     sd = dmax;
                     sl = up ? R.y : R.x;
                 } else {
-                    sl = s_out - sqrt(price * k0);                     // :334
+                    sl = s_out - (FAST ? fast_sqrt(price * k0) : sqrt(price * k0));   // :334
                     sd = dd;
                 }
             }
         }
+        return true;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void tail(bool up, double g, double yg, double sd, double sl, Trade& t) const
+    {
+        const double d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;
+        if (up) { t.d1 = d; t.l2 = sl; }                                   // :366-372
+        else { t.d2 = d; t.l1 = sl; }                                      // :386-391
+    }
+
+    // Lane-per-pool walk (segments whose walk lists are short, e.g. every BoundedProduct pool).
+    template <bool FAST>
+    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
+    {
+        bool up;
+        double g, yg, price, yp, sd, sl;
+        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl)) return;
         const int begin = up ? r.walk.x : r.walk.z;
         const int count = up ? r.walk.y : r.walk.w;
         for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
             double d, l;
-            list_tick(begin + j, price, d, l);
+            list_tick<FAST>(begin + j, price, yp, d, l);
             if (d == 0 || l == 0) break;                               // :363-365 (initial is false here)
             sd += d;
             sl += l;
         }
-        if (up) { t.d1 = sd / g; t.l2 = sl; }                          // :366-372
-        else { t.d2 = sd / g; t.l1 = sl; }                             // :386-391
+        tail<FAST>(up, g, yg, sd, sl, t);
     }
 };
 
@@ -360,40 +529,17 @@ struct UniV3CoopOps : UniV3Ops {
     // the faster form (all 64 lanes busy); cooperation pays for the sparse deep walks.
     // All 64 lanes must call this together (`valid` = this lane holds a pool).
     static constexpr int kCoopLanes = 4;   // stragglers left in a wavefront before it finishes them together
-    __device__ __forceinline__ void solve_wave(const Raw& r, bool valid, double v1, double v2, Trade& t) const
+    template <bool FAST>
+    __device__ __forceinline__ void solve_wave(const Raw& r, bool valid, const Px& px, Trade& t) const
     {
         const int lane = threadIdx.x & 63;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        bool trades = false, up = false, pending = false, nan_price = false;
-        double g = 1.0, price = 1.0, sd = 0.0, sl = 0.0;
+        bool trades = false, up = false, pending = false;
+        double g = 1.0, yg = 1.0, price = 1.0, yp = 1.0, sd = 0.0, sl = 0.0;
         int next = 0, remaining = 0;                                   // walk-list cursor of this lane's pool
         if (valid) {
-            const double cp = r.pg.x;
-            g = r.pg.y;
-            const double pr = v1 / v2;                                 // :340
-            if (pr != pr) {                                            // NaN prices propagate instead of "no trade"
-                nan_price = true;
-            } else if (!(g * cp <= pr && pr <= cp / g)) {              // :347-349
-                trades = true;
-                up = pr < g * cp;                                      // :351
-                price = up ? pr / g : 1.0 / (g * pr);                  // :361 / :381
-                // current tick: `initial` is true here unless the tick is empty (:355-358): no break test
-                const double k0 = r.ca.x;
-                if (k0 != 0) {
-                    const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
-                    const double dmax = up ? r.cb.y : r.cc;
-                    const double dd = sqrt(k0 / price) - s_in;         // :323
-                    if (dd > 0) {                                      // :325-327
-                        if (dd >= dmax) {                              // :330-332
-                            const double2 R = p.curR[r.i];
-                            sd = dmax;
-                            sl = up ? R.y : R.x;
-                        } else {
-                            sl = s_out - sqrt(price * k0);             // :334
-                            sd = dd;
-                        }
-                    }
-                }
+            trades = head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl);
+            if (trades) {
                 next = up ? r.walk.x : r.walk.z;
                 remaining = up ? r.walk.y : r.walk.w;
                 pending = remaining > 0;
@@ -410,13 +556,13 @@ struct UniV3CoopOps : UniV3Ops {
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
                     const int first = __shfl(next, src, 64), count = __shfl(remaining, src, 64);
-                    const double pr_src = __shfl(price, src, 64);
+                    const double pr_src = __shfl(price, src, 64), yp_src = __shfl(yp, src, 64);
                     bool stopped = false;
                     for (int base = 0; base < count && !stopped; base += 64) {
                         const int idx = base + lane;
                         const bool in = idx < count;
                         double d = 0.0, l = 0.0;
-                        if (in) list_tick(first + idx, pr_src, d, l);
+                        if (in) list_tick<FAST>(first + idx, pr_src, yp_src, d, l);
                         const unsigned long long stop = __ballot(in && (d == 0 || l == 0));
                         const int batch = count - base < 64 ? count - base : 64;
                         const int upto = stop ? __ffsll((long long)stop) - 1 : batch;
@@ -432,7 +578,7 @@ struct UniV3CoopOps : UniV3Ops {
             }
             if (pending) {                                             // :353 / :375, empty ticks elided
                 double d, l;
-                list_tick(next, price, d, l);
+                list_tick<FAST>(next, price, yp, d, l);
                 if (d == 0 || l == 0) {                                // :363-365 (initial is false here)
                     pending = false;
                 } else {
@@ -443,45 +589,22 @@ struct UniV3CoopOps : UniV3Ops {
                 }
             }
         }
-        if (trades) {
-            if (up) { t.d1 = sd / g; t.l2 = sl; }                      // :366-372
-            else { t.d2 = sd / g; t.l1 = sl; }                         // :386-391
-        }
-        if (nan_price) t.d1 = t.d2 = t.l1 = t.l2 = __builtin_nan("");
+        if (trades) tail<FAST>(up, g, yg, sd, sl, t);
     }
 };
 
 // ---------------------------------------------------------------------------------------------
 // The sweep: src/router.jl:38-42 fused with :79-83 and :98-100
 // ---------------------------------------------------------------------------------------------
-// Agent-scope (write-through / L1-bypassing, `sc1`) accesses for data exchanged between blocks of
-// ONE launch: MI355X_MICROARCH.md "inter-workgroup visibility" -- 8-byte agent-scope atomics on both
-// sides are a valid hand-off without any fence.
-__device__ __forceinline__ void store_through(double* p, double x)
-{
-    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_through(const double* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Trade stores (Δ, Λ: 16 B per lane, written once, never re-read by the sweep).  mode 0: plain
-// stores (the lines stay dirty in this XCD's L2 until evicted or until the end-of-kernel
-// write-back); 1: non-temporal; 2: write-through (`sc1`) -- the bytes leave during the sweep instead
-// of in a serial flush at its end (MI355X_MICROARCH.md, boundary row: + B / 6 TB/s for B dirty bytes).
+// Trade stores (Δ, Λ: 16 B per lane, written once, never re-read by the sweep) are write-through (`sc1`): the bytes
+// leave during the sweep instead of in a serial flush of dirty L2 lines at its end (MI355X_MICROARCH.md, boundary row:
+// + B / 6 TB/s for B dirty bytes; measured against plain and non-temporal stores in rounds 1 and 2: -1..-2 us per
+// 1M-pool sweep).
 typedef double d2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_pair(double2* dst, double x, double y, int mode)
+__device__ __forceinline__ void store_pair(double2* dst, double x, double y)
 {
-    if (mode == 2) {
-        d2v val = {x, y};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory");
-    } else if (mode == 1) {
-        __builtin_nontemporal_store(x, &dst->x);
-        __builtin_nontemporal_store(y, &dst->y);
-    } else {
-        *dst = make_double2(x, y);
-    }
+    d2v val = {x, y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory");
 }
 
 // One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
@@ -491,12 +614,13 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y, int
 // flows Λ−Δ are written to a flow array; Ψ is then PULLED per token over a token -> (pool, side)
 // incidence list built at upload (gather_chunks / token_fold below) -- no float atomics, fixed
 // summation order.  The partial rows carry only the dual scalar.
-// LDS of a sweeping block: v (the price vector), the netflow bins (one copy per wavefront, or one
+// LDS of a sweeping block: the prices {v, rcp_refined(v)} per token, the launch's fee table {γ, rcp_refined(γ)},
+// log v (launches with a log-space GeometricMean segment), the netflow bins (one copy per wavefront, or one
 // shared copy) and one slot per wavefront for the dual-scalar fold.
 struct SweepLds {
-    double* v_lds;     // [n_pad]
-    double* lv_lds;    // [n_pad] log v (only when a.need_logv)
-    double* gtab;      // [gtab_n] the launch's fee table (packed pool records)
+    double2* vy;       // [n_pad] {v, rcp_refined(v)}
+    double2* gtab;     // [gtab_n] {γ, rcp_refined(γ)}
+    double* lv;        // [n_pad] log v (only when a.need_logv)
     double* bins;      // [copies][n_pad]
     double* wsum;      // [kWaves]
     double* my_bins;   // this wavefront's copy
@@ -505,13 +629,20 @@ struct SweepLds {
 template <int BLOCK, bool GBINS>
 __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     SweepLds L;
-    L.v_lds = lds;
-    L.lv_lds = lds + a.n_pad;
-    L.bins = lds + (GBINS ? 0 : (a.need_logv ? 2 : 1) * a.n_pad);
-    L.wsum = GBINS ? lds : L.bins + (size_t)a.copies * a.n_pad;
-    L.gtab = L.wsum + BLOCK / 64;
+    if constexpr (GBINS) {
+        L.vy = nullptr;
+        L.gtab = nullptr;
+        L.lv = L.bins = L.my_bins = nullptr;
+        L.wsum = lds;
+        return L;
+    }
+    L.vy = reinterpret_cast<double2*>(lds);
+    L.gtab = L.vy + a.n_pad;
+    L.lv = reinterpret_cast<double*>(L.gtab + a.gtab_n);
+    L.bins = L.lv + (a.need_logv ? a.n_pad : 0);
+    L.wsum = L.bins + (size_t)a.copies * a.n_pad;
     L.my_bins = L.bins + (size_t)(a.copies == 1 ? 0 : (threadIdx.x >> 6)) * a.n_pad;
     return L;
 }
@@ -529,197 +660,198 @@ __device__ __forceinline__ bool wait_armed(const SweepArgs& a)
     }
 }
 
-// bins <- 0, fee table and v -> LDS, barrier.  Whole block.  Returns false only for a pre-armed launch that was
-// cancelled or gave up waiting for its prices (block-uniform).
+// bins <- 0, fee table and prices -> LDS, barrier.  Whole block.  Result (block-uniform): kStageLive unless this is a
+// pre-armed launch that was cancelled or gave up waiting for its prices; kStageFast when every staged price lies in the
+// window of the fast arithmetic.
+constexpr int kStageLive = 1, kStageFast = 2;
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ bool stage_prices(const SweepArgs& a, const SweepLds& L)
+__device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& L)
 {
-    const int tid = threadIdx.x;
-    const int n_stage = GBINS ? 0 : a.n;                 // tokens staged in LDS
-    const int n_zero = GBINS ? 0 : a.copies * a.n_pad;   // LDS bins to clear
-    const bool logs = !GBINS && a.need_logv;
-    const bool armed = !GBINS && a.arm_word != nullptr;   // kernel argument: block-uniform
-    if (!armed) {
-        // prices first: their loads are in flight while the bins are cleared
-        for (int j = tid; j < n_stage; j += BLOCK) {
-            const double vj = a.v[j];
-            L.v_lds[j] = vj;
-            if (logs) L.lv_lds[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
-        }
-        for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
-        if (!GBINS)
-            for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
+    if constexpr (GBINS) {
         __syncthreads();
-        return true;
+        return kStageLive;
     }
-    // pre-armed launch: everything that does not need the prices first, then the wait
-    for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
-    for (int j = tid; j < a.gtab_n; j += BLOCK) L.gtab[j] = a.gtab[j];
-    if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
-    __syncthreads();
-    const bool live = L.wsum[0] != 0.0;
-    for (int j = tid; j < n_stage; j += BLOCK) {
-        // the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
-        const double vj = __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        L.v_lds[j] = vj;
-        if (logs) L.lv_lds[j] = log(vj);
+    const int tid = threadIdx.x;
+    const int n_zero = a.copies * a.n_pad;                // LDS bins to clear
+    const bool logs = a.need_logv != 0;
+    const bool armed = a.arm_word != nullptr;             // kernel argument: block-uniform
+    bool live = true;
+    if (armed) {
+        // pre-armed launch: everything that does not need the prices first, then the wait
+        for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+        for (int j = tid; j < a.gtab_n; j += BLOCK) {
+            const double g = a.gtab[j];
+            L.gtab[j] = make_double2(g, rcp_refined(g));
+        }
+        if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
+        __syncthreads();
+        live = L.wsum[0] != 0.0;
     }
-    __syncthreads();
-    return live;
+    bool in_window = true;
+    for (int j = tid; j < a.n; j += BLOCK) {
+        // armed: the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
+        const double vj = armed ? __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.v[j];
+        L.vy[j] = make_double2(vj, rcp_refined(vj));
+        in_window = in_window && in_fast_window(vj);
+        if (logs) L.lv[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
+    }
+    if (!armed) {
+        // the price loads are in flight while the bins are cleared
+        for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
+        for (int j = tid; j < a.gtab_n; j += BLOCK) {
+            const double g = a.gtab[j];
+            L.gtab[j] = make_double2(g, rcp_refined(g));
+        }
+    }
+    const int all_in = __syncthreads_and(in_window ? 1 : 0);
+    return (live ? kStageLive : 0) | (all_in ? kStageFast : 0);
 }
 
-// The tile loop of one pool family over a SHARE of a segment: lane `sub_tid` of a group of
-// `sub_block` threads (the whole block, or the wavefronts a fused launch gives this family) takes
-// pools (bid + k·nblocks)·sub_block + sub_tid, k = 0, 1, ...  Returns this lane's dual-scalar part.
-// STAGE: call stage_prices() after the first tile's loads have been issued (hides that HBM round
-// trip behind the staging barrier); otherwise the caller has staged already.
-template <class Ops, bool MAT, int U, int BLOCK, bool GBINS, bool STAGE>
-__device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
-                                              int sub_tid, int sub_block, bool& live_out)
+// One pool: prices from LDS, closed form, trade record, dual scalar, netflow bins.
+template <class Ops, bool MAT, bool GBINS, bool FAST>
+__device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a, const SweepLds& L,
+                                             const typename Ops::Raw& raw_in, int64_t i, bool valid, double& acc)
 {
-    double acc = 0.0;
-    live_out = true;
-    // `valid` is false only for wave-cooperative families, whose lanes without a pool still have to
-    // take part in the wavefront-wide phases of solve_wave.
-    auto process = [&](const typename Ops::Raw& raw_in, int64_t i, bool valid) {
-        typename Ops::Raw raw = raw_in;
-        if constexpr (!GBINS) ops.resolve(raw, L.gtab);   // packed records: fee table index -> fee
-        int2 tok = make_int2(0, 0);
-        if (valid) tok = ops.tokens(raw);
-        double v1, v2;                                   // v[r.cfmms[i].Ai]
-        if constexpr (GBINS) { v1 = a.v[tok.x]; v2 = a.v[tok.y]; }
-        else { v1 = L.v_lds[tok.x]; v2 = L.v_lds[tok.y]; }
-        Trade t;
-        if constexpr (Ops::kWaveCooperative) {
-            ops.solve_wave(raw, valid, v1, v2, t);
-        } else if constexpr (Ops::kNeedsLogPrices) {
-            double dlv;
-            if constexpr (GBINS) dlv = log(v2 / v1);     // large markets: v is not staged, one logarithm per pool
-            else dlv = L.lv_lds[tok.y] - L.lv_lds[tok.x];
-            ops.solve(raw, v1, v2, dlv, t);
-        } else {
-            ops.solve(raw, v1, v2, t);
-        }
-        if (!valid) return;
-        if (MAT) {
-            if (a.compact) {   // one 16-byte record per pool (see SweepArgs)
-                // a record can carry one direction whose two values have a clear sign bit (NaN payloads survive the
-                // sign flip) while the other direction is exactly +0; everything else -- both directions trading and
-                // the tiny negative / -0.0 values the reference's tick arithmetic produces on degenerate UniV3
-                // boundaries -- takes the overflow rows, so the encoding is lossless bit for bit
-                const int d1h = __double2hiint(t.d1), d2h = __double2hiint(t.d2), l1h = __double2hiint(t.l1), l2h = __double2hiint(t.l2);
-                const int z1 = d2h | __double2loint(t.d2) | l1h | __double2loint(t.l1);   // 0 <=> Δ₂ and Λ₁ are +0.0
-                const int z2 = d1h | __double2loint(t.d1) | l2h | __double2loint(t.l2);   // 0 <=> Δ₁ and Λ₂ are +0.0
-                const bool dir1 = (z1 == 0) & ((d1h | l2h) >= 0);
-                const bool dir2 = (z2 == 0) & ((d2h | l1h) >= 0);
-                double ra = t.d1, rb = t.l2;
-                if (!dir1) {
-                    if (dir2) {
-                        ra = -t.d2;          // sign bit set (−0.0 included): direction 2
-                        rb = t.l1;
-                    } else {
-                        a.Lambda[i] = make_double2(t.d1, t.d2);
-                        a.Over[i] = make_double2(t.l1, t.l2);
-                        ra = 0.0;
-                        rb = -1.0;
-                    }
+    typename Ops::Raw raw = raw_in;
+    if constexpr (!GBINS) ops.resolve(raw, L.gtab);   // packed records: {tokens, fee-table index} -> tokens, fee
+    int2 tok = make_int2(0, 0);
+    if (valid) tok = ops.tokens(raw);
+    Px px;                                            // v[r.cfmms[i].Ai]
+    px.yg = raw.yg;
+    if constexpr (GBINS) {
+        px.v1 = a.v[tok.x];
+        px.v2 = a.v[tok.y];
+        px.y1 = px.y2 = 0.0;
+        px.dlv = Ops::kNeedsLogPrices ? log(px.v2 / px.v1) : 0.0;   // large markets: v is not staged, one logarithm per pool
+    } else {
+        const double2 a1 = L.vy[tok.x], a2 = L.vy[tok.y];
+        px.v1 = a1.x; px.y1 = a1.y;
+        px.v2 = a2.x; px.y2 = a2.y;
+        px.dlv = 0.0;
+        if constexpr (Ops::kNeedsLogPrices) px.dlv = L.lv[tok.y] - L.lv[tok.x];
+    }
+    Trade t;
+    if constexpr (Ops::kWaveCooperative) ops.template solve_wave<FAST>(raw, valid, px, t);
+    else ops.template solve<FAST>(raw, px, t);
+    if (!valid) return;
+    const double v1 = px.v1, v2 = px.v2;
+    if (MAT) {
+        if (a.compact) {   // one 16-byte record per pool (see SweepArgs)
+            // a record can carry one direction whose two values have a clear sign bit (NaN payloads survive the
+            // sign flip) while the other direction is exactly +0; everything else -- both directions trading and
+            // the tiny negative / -0.0 values the reference's tick arithmetic produces on degenerate UniV3
+            // boundaries -- takes the overflow rows, so the encoding is lossless bit for bit
+            const int d1h = __double2hiint(t.d1), d2h = __double2hiint(t.d2), l1h = __double2hiint(t.l1), l2h = __double2hiint(t.l2);
+            const int z1 = d2h | __double2loint(t.d2) | l1h | __double2loint(t.l1);   // 0 <=> Δ₂ and Λ₁ are +0.0
+            const int z2 = d1h | __double2loint(t.d1) | l2h | __double2loint(t.l2);   // 0 <=> Δ₁ and Λ₂ are +0.0
+            const bool dir1 = (z1 == 0) & ((d1h | l2h) >= 0);
+            const bool dir2 = (z2 == 0) & ((d2h | l1h) >= 0);
+            double ra = t.d1, rb = t.l2;
+            if (!dir1) {
+                if (dir2) {
+                    ra = -t.d2;          // sign bit set (−0.0 included): direction 2
+                    rb = t.l1;
+                } else {
+                    a.Lambda[i] = make_double2(t.d1, t.d2);
+                    a.Over[i] = make_double2(t.l1, t.l2);
+                    ra = 0.0;
+                    rb = -1.0;
                 }
-                store_pair(a.Delta + i, ra, rb, a.nt_stores);
-            } else {
-                store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
-                store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
             }
-        }
-        // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
-        acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
-        // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
-        const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
-        if constexpr (GBINS) {
-            a.gflow[i] = make_double2(f1, f2);
+            store_pair(a.Delta + i, ra, rb);
         } else {
-            if (f1 != 0.0) atomicAdd(&L.my_bins[tok.x], f1);   // ds_add_f64
-            if (f2 != 0.0) atomicAdd(&L.my_bins[tok.y], f2);
+            store_pair(a.Delta + i, t.d1, t.d2);
+            store_pair(a.Lambda + i, t.l1, t.l2);
         }
-    };
+    }
+    // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])
+    acc += (t.l1 * v1 + t.l2 * v2) - (t.d1 * v1 + t.d2 * v2);
+    // src/router.jl:99 / :115  G[Ai] .+= Λ .- Δ
+    const double f1 = t.l1 - t.d1, f2 = t.l2 - t.d2;
+    if constexpr (GBINS) {
+        a.gflow[i] = make_double2(f1, f2);
+    } else {
+        if (f1 != 0.0) atomicAdd(&L.my_bins[tok.x], f1);   // ds_add_f64
+        if (f2 != 0.0) atomicAdd(&L.my_bins[tok.y], f2);
+    }
+}
 
-    if constexpr (U == 1) {
-        // One pool per lane per tile.  The first tile's pool state is requested before v and the
-        // bins are staged in LDS, so that HBM round trip is not exposed behind the barrier.
-        // (Requesting tile k+1 before solving tile k was measured three times: round 1, -10 %; round 2 with an
-        // UNCONDITIONAL next-tile load -- a conditional one makes the compiler wait for it at the join,
-        // before the arithmetic -- and the overlap verified in the ISA: +-0 cache-warm on every workload, with
-        // or without s_setprio around the load issue (profiles/r02_sweep_decomposition.txt), and again +-0 with
-        // the pool state coming from HBM (config5: 7 % slower).  Not kept: it only costs registers.)
-        // Tile order alternates between consecutive sweeps (a.reverse): block-strided "phases" are walked
-        // first-to-last by one sweep and last-to-first by the next, so each sweep begins on the pool data the
-        // previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
-        // 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
-        // same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
-        const int64_t stride = (int64_t)nblocks * sub_block;
-        const int64_t i0 = (int64_t)bid * sub_block + sub_tid;
-        int64_t left = i0 < a.m ? (a.m - i0 + stride - 1) / stride : 0;      // tiles of this lane
-        const int64_t step = a.reverse ? -stride : stride;
-        int64_t i = a.reverse ? i0 + (left - 1) * stride : i0;
-        typename Ops::Raw cur = {};
-        bool ok = left > 0;
-        if (ok) cur = ops.load(i);
-        if constexpr (STAGE) {
-            if (!stage_prices<BLOCK, GBINS>(a, L)) {       // a pre-armed launch that is not needed (or gave up)
-                ok = false;
-                live_out = false;
-                acc = __builtin_nan("");                   // poisons the dual column should anyone fold this row
-            }
-        }
-        if constexpr (Ops::kWaveCooperative) {
-            while (__any(ok)) {                          // the wavefront stays together
-                process(cur, i, ok);
-                if (ok) {
-                    i += step;
-                    ok = --left > 0;
-                    if (ok) cur = ops.load(i);
-                }
-            }
-        } else {
-            while (ok) {
-                process(cur, i, true);
+// The tile loop of one pool family over a block's share of a segment: lane tid takes pools
+// (bid + k·nblocks)·BLOCK + tid, k = 0, 1, ...  Returns this lane's dual-scalar part.
+// The first tile's pool state is requested BEFORE v and the bins are staged in LDS, so that HBM round trip is not
+// exposed behind the staging barrier.  Tile order alternates between consecutive sweeps (a.reverse): block-strided
+// "phases" are walked first-to-last by one sweep and last-to-first by the next, so each sweep begins on the pool data
+// the previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
+// 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
+// same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
+#ifndef CFMM_PREFETCH
+#define CFMM_PREFETCH 0   // 1: tile k+1's loads are issued before tile k is solved (A/B builds)
+#endif
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FAST>
+__device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, const SweepLds& L, typename Ops::Raw cur,
+                                          int64_t i, int64_t step, int64_t left, double& acc)
+{
+    bool ok = left > 0;
+    if constexpr (Ops::kWaveCooperative) {
+        while (__any(ok)) {                          // the wavefront stays together
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, ok, acc);
+            if (ok) {
                 i += step;
                 ok = --left > 0;
                 if (ok) cur = ops.load(i);
             }
         }
+    } else if constexpr (CFMM_PREFETCH != 0) {
+        while (ok) {
+            const bool more = left > 1;
+            // unconditional request (a conditional one makes the compiler wait for it at the join, before the
+            // arithmetic): the last tile re-requests itself, a cache hit
+            const typename Ops::Raw nxt = ops.load(more ? i + step : i);
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
+            cur = nxt;
+            i += step;
+            --left;
+            ok = more;
+        }
     } else {
-        bool live = true;
-        if constexpr (STAGE) live = stage_prices<BLOCK, GBINS>(a, L);
-        if (!live) acc = __builtin_nan("");
-        live_out = live;
-        const int64_t tile_pools = (int64_t)sub_block * U;
-        const int64_t n_tiles = (a.m + tile_pools - 1) / tile_pools;
-        const int64_t mine = live && bid < n_tiles ? (n_tiles - bid + nblocks - 1) / nblocks : 0;
-        for (int64_t k = 0; k < mine; ++k) {   // uniform trip count within the group
-            const int64_t tile = bid + (a.reverse ? mine - 1 - k : k) * nblocks;
-            const int64_t base = tile * tile_pools + sub_tid;
-            typename Ops::Raw raw[U] = {};
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t i = base + (int64_t)u * sub_block;
-                ok[u] = i < a.m;
-                if (ok[u]) raw[u] = ops.load(i);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (Ops::kWaveCooperative || ok[u]) process(raw[u], base + (int64_t)u * sub_block, ok[u]);
+        while (ok) {
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
+            i += step;
+            ok = --left > 0;
+            if (ok) cur = ops.load(i);
         }
     }
+}
+
+template <class Ops, bool MAT, int BLOCK, bool GBINS>
+__device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
+                                              bool& live_out)
+{
+    double acc = 0.0;
+    const int64_t stride = (int64_t)nblocks * BLOCK;
+    const int64_t i0 = (int64_t)bid * BLOCK + threadIdx.x;
+    int64_t left = i0 < a.m ? (a.m - i0 + stride - 1) / stride : 0;      // tiles of this lane
+    const int64_t step = a.reverse ? -stride : stride;
+    const int64_t i = a.reverse ? i0 + (left - 1) * stride : i0;
+    typename Ops::Raw cur = {};
+    if (left > 0) cur = ops.load(i);
+    const int staged = stage_prices<BLOCK, GBINS>(a, L);
+    live_out = (staged & kStageLive) != 0;
+    if (!live_out) {                                  // a pre-armed launch that is not needed (or gave up)
+        left = 0;
+        acc = __builtin_nan("");                      // poisons the dual column should anyone fold this row
+    }
+    const bool fast = !GBINS && a.fast_ok != 0 && (staged & kStageFast) != 0;   // block-uniform
+    if (fast) tile_loop<Ops, MAT, BLOCK, GBINS, !GBINS>(ops, a, L, cur, i, step, left, acc);
+    else tile_loop<Ops, MAT, BLOCK, GBINS, false>(ops, a, L, cur, i, step, left, acc);
     return acc;
 }
 
 // Block epilogue: fold the dual scalar (lanes by wave shuffles, waves through LDS, fixed order), fold
 // the bin copies in a fixed order and write the block's partial row.
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id, bool live = true)
+__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id)
 {
-    constexpr int kBlock = BLOCK;
     constexpr int kWaves = BLOCK / 64;
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -730,245 +862,41 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
     double* row = a.partials + (size_t)row_id * (n_cols + 1);
-    // the row is folded inside THIS launch (not for a cancelled pre-armed launch: nobody will fold, and the arrival
-    // counters must stay zero for the next launch)
-    const bool publish = !GBINS && a.fold_blocks > 0 && live;
-    for (int j = tid; j < n_cols; j += kBlock) {
+    for (int j = tid; j < n_cols; j += BLOCK) {
         double s = L.bins[j];
         for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
-        if (publish) store_through(row + j, s);
-        else row[j] = s;
+        row[j] = s;
     }
     if (tid == 0) {
         double s = L.wsum[0];
         for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
-        if (publish) store_through(row + n_cols, s);
-        else row[n_cols] = s;
-    }
-    if (publish) {
-        // Hand the row to the fold blocks of this launch: the row went out with write-through
-        // (agent-scope) stores, so no release fence -- a buffer_wbl2 here would also have to write
-        // back this XCD's share of the 32 MB of trade stores (measured 2.5x slower per step in
-        // round 1).  Every storing wavefront drains its own stores, then ONE lane arrives.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_fetch_add(a.sync + (row_id % kArriveShards) * kSyncStride, 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        row[n_cols] = s;
     }
 }
 
 // One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
 // row goes to partials[row_id].
-template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
-__device__ __forceinline__ bool sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
+template <class Ops, bool MAT, int BLOCK, bool GBINS = false>
+__device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
     bool live;
-    const double acc = sweep_tiles<Ops, MAT, U, BLOCK, GBINS, true>(ops, a, L, bid, nblocks, (int)threadIdx.x, BLOCK, live);
-    finish_row<BLOCK, GBINS>(a, L, acc, row_id, live);
-    return live;
+    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS>(ops, a, L, bid, nblocks, live);
+    finish_row<BLOCK, GBINS>(a, L, acc, row_id);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Row fold: out[j] = sum over rows of partials[row][j]  (src/router.jl:81-83, :98-100 summed over blocks)
-// ---------------------------------------------------------------------------------------------
-// One block owns kReduceCols adjacent columns (one 64 B line of every row).  lane = (row-lane r,
-// column c): a wavefront holds 8 row-lanes x 8 columns.  Each lane sums its rows in increasing
-// order (kBatch independent loads in flight), the row-lanes of a wavefront are folded by a fixed
-// shuffle tree, the wavefronts by a fixed-order LDS pass: bit-reproducible for a fixed geometry.
-// COHERENT: rows are read with agent-scope loads (they were published inside the same launch).
-template <int BLOCK, bool COHERENT>
-__device__ __forceinline__ double fold_columns(const double* partials, int rows, int n1, int colblock, double* red)
-{
-    constexpr int kRowLanes = BLOCK / kReduceCols;
-    constexpr int kWaves = BLOCK / 64;
-    constexpr int kBatch = 8;
-    const int c = threadIdx.x % kReduceCols;
-    const int r = threadIdx.x / kReduceCols;
-    const int col = colblock * kReduceCols + c;
-    double s = 0.0;
-    if (col < n1) {
-        const double* p = partials + col;
-        auto ld = [&](int row) -> double {
-            if constexpr (COHERENT) return load_through(p + (size_t)row * n1);
-            else return p[(size_t)row * n1];
-        };
-        int row = r;
-        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
-            double x[kBatch];
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) x[b] = ld(row + b * kRowLanes);
-#pragma unroll
-            for (int b = 0; b < kBatch; ++b) s += x[b];
-        }
-        for (; row < rows; row += kRowLanes) s += ld(row);
-    }
-#pragma unroll
-    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
-    __syncthreads();
-    double tsum = 0.0;
-    if (threadIdx.x < kReduceCols) {
-        tsum = red[c];
-        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
-    }
-    return tsum;   // valid in threads [0, kReduceCols) with col < n1
-}
-
-// Tail of a fold block: write its (up to) kReduceCols outputs and, when asked, take part in the
-// fold blocks' "done" ticket: the LAST fold block to get here (a) zeroes the arrival counters of an
-// in-launch fold for the next launch and (b) raises the host-visible completion flag.  For (b) the
-// outputs live in mapped host memory and are written with system-scope (write-through) stores that
-// every block drains before it takes its ticket, so the flag -- a later posted write on the same
-// PCIe path -- cannot overtake them.
-// host_seq with kHostGranules set: host_flag points to 2·n1 8-byte words in mapped host memory and the outputs travel as
-// SELF-VALIDATING granules {tag = low 32 bits of host_seq, 32 bits of the double} (two per column, as between peers in
-// reduce_gather): the host re-reads them until all carry the tag -- no drain of the output stores, no ticket, no flag.
-__device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double* out, unsigned* sync, int fold_blocks,
-                                            bool reset_arrivals, unsigned long long* host_flag,
-                                            unsigned long long host_seq)
-{
-    const int tid = threadIdx.x;
-    const int col = blockIdx.x * kReduceCols + tid;
-    const bool granules = host_flag != nullptr && (host_seq & kHostGranules) != 0;
-    if (granules) {
-        // the block's 8 columns leave as 16 granules = 128 contiguous, 128-byte aligned bytes written by ONE store
-        // instruction (lane 2c + h carries half h of column c): two full 64-byte lines on the PCIe side -- a line
-        // written in pieces costs a read-modify-write per piece at the host's memory controller (measured: 2x slower
-        // evaluations).  Columns past n1 travel as zeros so that the last block writes full lines too.
-        if (tid < 64) {
-            const double val = (tid < kReduceCols && col < n1) ? (ok ? tsum : __builtin_nan("")) : 0.0;
-            const long long bits = __shfl(__double_as_longlong(val), (tid >> 1) & (kReduceCols - 1), 64);
-            if (tid < 2 * kReduceCols) {
-                const unsigned long long tag = (host_seq & 0xffffffffull) << 32, u = (unsigned long long)bits;
-                __hip_atomic_store(host_flag + 2 * (size_t)blockIdx.x * kReduceCols + tid,
-                                   tag | ((tid & 1) ? (u >> 32) : (u & 0xffffffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        host_flag = nullptr;                               // nothing left to signal
-    } else if (tid < kReduceCols && col < n1) {
-        const double val = ok ? tsum : __builtin_nan("");
-        if (host_flag) __hip_atomic_store(out + col, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else out[col] = val;
-    }
-    if (!reset_arrivals && !host_flag) return;
-    if (tid < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's outputs have left
-        if (tid == 0) {
-            unsigned* done = sync + kArriveShards * kSyncStride;
-            const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == (unsigned)fold_blocks - 1u) {         // last fold block: every output is out
-                if (reset_arrivals)
-                    for (int k = 0; k < kArriveShards; ++k)
-                        __hip_atomic_store(sync + k * kSyncStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (host_flag) __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-}
-
-// The fold blocks of a sweep launch (blockIdx.x < a.fold_blocks).  Wavefront 0 polls the arrival
-// counters (relaxed agent-scope loads, s_sleep between polls, bounded) until all `nprod` sweeping
-// blocks have published; the rows are then read with agent-scope loads (the producers stored
-// agent-scope: no acquire fence needed) and folded exactly as reduce_partials does.  The last fold
-// block to finish zeroes the counters again, so the next launch on the stream starts clean, and --
-// when the output lives in mapped host memory -- raises the host-visible completion flag.
-template <int BLOCK>
-__device__ __forceinline__ void fold_role(const SweepArgs& a, int nprod)
-{
-    extern __shared__ double lds[];
-    double* red = lds;                                   // [BLOCK/64][kReduceCols]
-    int* okp = reinterpret_cast<int*>(lds + (BLOCK / 64) * kReduceCols);
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        bool ok = true;
-        for (unsigned spins = 0;; ++spins) {
-            unsigned cnt = tid < kArriveShards
-                               ? __hip_atomic_load(a.sync + tid * kSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-            if (cnt >= (unsigned)nprod) break;
-            if (spins > (1u << 22)) { ok = false; break; }   // seconds: a sweeping block died; poison the output
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (tid == 0) *okp = ok ? 1 : 0;
-    }
-    __syncthreads();
-    const bool ok = *okp != 0;
-    __syncthreads();                                     // okp shares no storage with red, but keep phases apart
-    const int n1 = a.n + 1;
-    const double tsum = fold_columns<BLOCK, true>(a.partials, nprod, n1, blockIdx.x, red);
-    fold_finish(tsum, ok, n1, a.fold_out, a.sync, a.fold_blocks, true, a.host_flag, a.host_seq);
-}
-
-template <class Ops, bool MAT, int U, int BLOCK, bool GBINS = false>
+template <class Ops, bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    if constexpr (!GBINS) {
-        if ((int)blockIdx.x < a.fold_blocks) {
-            fold_role<BLOCK>(a, (int)gridDim.x - a.fold_blocks);
-            return;
-        }
-    }
-    const int fb = GBINS ? 0 : a.fold_blocks;
-    (void)sweep_body<Ops, MAT, U, BLOCK, GBINS>(ops, a, (int)blockIdx.x - fb, (int)gridDim.x - fb, (int)blockIdx.x - fb);
+    sweep_body<Ops, MAT, BLOCK, GBINS>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
-// Several segments (pool families) in ONE launch: block b works on segment b % nseg, so
-// HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean / UniV3 blocks are co-resident on
-// every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
+// Several segments (pool families) in ONE launch, so HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean /
+// UniV3 blocks are co-resident on every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
 template <bool MAT, int BLOCK, bool GBINS = false>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
-    const int fb = GBINS ? 0 : ma.common.fold_blocks;
-    if (!GBINS && (int)blockIdx.x < fb) {
-        fold_role<BLOCK>(ma.common, (int)gridDim.x - fb);
-        return;
-    }
-    const int bidx = (int)blockIdx.x - fb;
-    if (ma.wave_split) {
-        // Every block sweeps a share of EVERY segment: its wavefronts are dealt to the pool families
-        // (nseg = 2, 8 wavefronts: 0-3 ProductTwoCoin, 4-7 GeometricMean), so bandwidth-bound and
-        // arithmetic-bound wavefronts share every CU -- and, because a block's wavefronts go to the
-        // SIMDs in turn, every SIMD -- whatever the dispatcher's block placement is.
-        constexpr int kWaves = BLOCK / 64;
-        const int per = kWaves / ma.nseg;                 // wavefronts per family (host guarantees kWaves % nseg == 0)
-        const int fam = ((int)threadIdx.x >> 6) / per;
-        const int sub_block = per * 64, sub_tid = (int)threadIdx.x - fam * sub_block;
-        const int G = (int)gridDim.x - fb;
-        const MultiSeg& sg = ma.seg[fam];
-        SweepArgs a = ma.common;
-        a.m = sg.m;
-        a.Delta = sg.Delta;
-        a.Lambda = sg.Lambda;
-        a.Over = sg.Over;
-        a.gflow = sg.gflow;
-        const SweepLds L = carve_lds<BLOCK, GBINS>(a);
-        (void)stage_prices<BLOCK, GBINS>(a, L);           // never armed (host side: wave_split excludes arming)
-        double acc = 0.0;
-        bool ws_live;
-        switch (sg.kind) {                                // wavefront-uniform
-        case 0:
-            acc = sweep_tiles<ProductOps, MAT, 1, BLOCK, GBINS, false>(ProductOps{sg.pools.p}, a, L, bidx, G, sub_tid, sub_block, ws_live);
-            break;
-        case 1:
-            acc = sweep_tiles<GeoMeanLogOps, MAT, 1, BLOCK, GBINS, false>(GeoMeanLogOps{sg.pools.g}, a, L, bidx, G, sub_tid, sub_block, ws_live);
-            break;
-        default:
-            {
-                UniV3CoopOps ops;
-                ops.p = sg.pools.u;
-                acc = sweep_tiles<UniV3CoopOps, MAT, 1, BLOCK, GBINS, false>(ops, a, L, bidx, G, sub_tid, sub_block, ws_live);
-            }
-            break;
-        }
-        finish_row<BLOCK, GBINS>(a, L, acc, bidx);
-        return;
-    }
+    const int bidx = (int)blockIdx.x;
     int sidx, local, nblocks;
     if (ma.xcd_map) {
         // XCD-aware, cost-weighted block -> segment map.  Blocks are dealt round-robin to the 8 XCDs (block
@@ -984,53 +912,114 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         sidx = ma.pattern[p];
         const int w = ma.seg_w[sidx];
         local = (q * w + ma.rank[p]) * 8 + x;
-        nblocks = (((int)gridDim.x - fb) >> 8) * w * 8;
-    } else {
-        nblocks = ((int)gridDim.x - fb) / ma.nseg;
+        nblocks = ((int)gridDim.x >> 8) * w * 8;
+    } else {   // small grids (not a multiple of 256 blocks): block b -> segment b % nseg
+        nblocks = (int)gridDim.x / ma.nseg;
         sidx = bidx % ma.nseg;
         local = bidx / ma.nseg;
     }
     const MultiSeg& sg = ma.seg[sidx];
     SweepArgs a = ma.common;
     a.m = sg.m;
+    a.fast_ok = sg.fast_ok;
     a.Delta = sg.Delta;
     a.Lambda = sg.Lambda;
     a.Over = sg.Over;
     a.gflow = sg.gflow;
-    bool live;
     switch (sg.kind) {
     case 0:
-        live = sweep_body<ProductOps, MAT, 1, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
+        sweep_body<ProductOps, MAT, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
         break;
     case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
-        live = sweep_body<GeoMeanLogOps, MAT, 1, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
+        sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
         {   // the cooperative variant serves both shallow and deep segments here (no register cost:
             // the fused kernel's footprint is set by the GeometricMean branch)
             UniV3CoopOps ops;
             ops.p = sg.pools.u;
-            live = sweep_body<UniV3CoopOps, MAT, 1, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
+            sweep_body<UniV3CoopOps, MAT, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
         }
         break;
     }
-    (void)live;
 }
 
-// The same fold as its own launch (several sweep launches per evaluation, or "inline_fold" = 0).
-// Launched with the sweep's block size, so both forms sum in the same order (bit-identical results).
+// ---------------------------------------------------------------------------------------------
+// Row fold: out[j] = sum over rows of partials[row][j]  (src/router.jl:81-83, :98-100 summed over blocks)
+// ---------------------------------------------------------------------------------------------
+// One block owns kReduceCols adjacent columns (one 64 B line of every row).  lane = (row-lane r,
+// column c): a wavefront holds 8 row-lanes x 8 columns.  Each lane sums its rows in increasing
+// order (kBatch independent loads in flight), the row-lanes of a wavefront are folded by a fixed
+// shuffle tree, the wavefronts by a fixed-order LDS pass: bit-reproducible for a fixed geometry.
+__device__ __forceinline__ double fold_columns(const double* __restrict__ partials, int rows, int n1, int colblock, double* red)
+{
+    constexpr int kRowLanes = kFoldBlock / kReduceCols;
+    constexpr int kWaves = kFoldBlock / 64;
+    constexpr int kBatch = 4;
+    const int c = threadIdx.x % kReduceCols;
+    const int r = threadIdx.x / kReduceCols;
+    const int col = colblock * kReduceCols + c;
+    double s = 0.0;
+    if (col < n1) {
+        const double* p = partials + col;
+        int row = r;
+        for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
+            double x[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) s += x[b];
+        }
+        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
+    }
+#pragma unroll
+    for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < kReduceCols) red[wave * kReduceCols + lane] = s;
+    __syncthreads();
+    double tsum = 0.0;
+    if (threadIdx.x < kReduceCols) {
+        tsum = red[c];
+        for (int k = 1; k < kWaves; ++k) tsum += red[k * kReduceCols + c];
+    }
+    return tsum;   // valid in threads [0, kReduceCols) with col < n1
+}
+
+// Tail of a fold block: its (up to) kReduceCols outputs go to `out` (plain stores, device consumers) or -- host.gran
+// set -- to mapped host memory as SELF-VALIDATING granules {tag, 32 bits of the double} (two per column): the block's 8
+// columns leave as 16 granules = 128 contiguous, 128-byte aligned bytes written by ONE store instruction (lane 2c + h
+// carries half h of column c): two full 64-byte lines on the PCIe side -- a line written in pieces costs a
+// read-modify-write per piece at the host's memory controller (measured: 2x slower evaluations).  Columns past n1
+// travel as zeros so that the last block writes full lines too.  The host re-reads the granules until all carry the
+// tag: no drain of the output stores, no ticket, no flag word.  Wavefront 0 only; tsum valid in lanes [0, kReduceCols).
+__device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double* out, HostOut host)
+{
+    const int tid = threadIdx.x;
+    if (tid >= 64) return;
+    const int col = blockIdx.x * kReduceCols + tid;
+    if (host.gran) {
+        const double val = (tid < kReduceCols && col < n1) ? (ok ? tsum : __builtin_nan("")) : 0.0;
+        const long long bits = __shfl(__double_as_longlong(val), (tid >> 1) & (kReduceCols - 1), 64);
+        if (tid < 2 * kReduceCols) {
+            const unsigned long long tag = (host.tag & 0xffffffffull) << 32, u = (unsigned long long)bits;
+            __hip_atomic_store(host.gran + 2 * (size_t)blockIdx.x * kReduceCols + tid,
+                               tag | ((tid & 1) ? (u >> 32) : (u & 0xffffffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else if (tid < kReduceCols && col < n1) {
+        out[col] = ok ? tsum : __builtin_nan("");
+    }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int rows, int n1,
-                                                         double* __restrict__ out, unsigned* sync,
-                                                         unsigned long long* host_flag, unsigned long long host_seq,
-                                                         ArmWord arm)
+                                                         double* __restrict__ out, HostOut host, ArmWord arm)
 {
     __shared__ double red[(BLOCK / 64) * kReduceCols];
     // the fold of a pre-armed evaluation that was cancelled (or never got its prices) has nothing to publish; the
-    // word cannot change between the threads' loads: the host moves on only after this launch's completion flag
+    // word cannot change between the threads' loads: the host moves on only after this launch's outputs
     if (arm.word && __hip_atomic_load(arm.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != arm.seq) return;
-    const double tsum = fold_columns<BLOCK, false>(partials, rows, n1, blockIdx.x, red);
-    fold_finish(tsum, true, n1, out, sync, (int)gridDim.x, false, host_flag, host_seq);
+    const double tsum = fold_columns(partials, rows, n1, blockIdx.x, red);
+    fold_finish(tsum, true, n1, out, host);
 }
 
 // Fold + all-reduce in one launch (sharded runs, see sweep.h).  The exchange uses self-validating
@@ -1047,7 +1036,10 @@ __global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict_
                                                        double* __restrict__ out, PeerSet ps)
 {
     __shared__ double red[(BLOCK / 64) * kReduceCols];
-    const double tsum = fold_columns<BLOCK, false>(partials, rows, n1, blockIdx.x, red);
+    // a cancelled pre-armed evaluation is cancelled on EVERY rank (the ranks run the same solver in lockstep):
+    // nobody publishes, nobody waits, and the sequence number is reused by the next launch
+    if (ps.arm.word && __hip_atomic_load(ps.arm.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ps.arm.seq) return;
+    const double tsum = fold_columns(partials, rows, n1, blockIdx.x, red);
     const int tid = threadIdx.x;
     if (tid >= 64) return;                                // the exchange is wavefront 0's business
     const int parity = (int)(ps.seq & 1ull);
@@ -1086,7 +1078,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict_
     ok = __all(ok);
     double s = 0.0;                                       // rank order on every rank: bit-identical results
     for (int p = 0; p < ps.world; ++p) s += __shfl(p < 8 ? x[0] : x[1], (p & 7) * kReduceCols + c, 64);
-    fold_finish(s, ok, n1, out, ps.sync, (int)gridDim.x, false, ps.host_flag, ps.host_seq);
+    fold_finish(s, ok, n1, out, ps.host);
 }
 
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat
@@ -1163,25 +1155,19 @@ static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEve
 
 size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab_n)
 {
-    // the fold blocks of the same launch need [block/64][kReduceCols] doubles + one flag word
-    const size_t sweep = (size_t)n_pad * ((need_logv ? 2 : 1) + copies) + block / 64 + (size_t)gtab_n;
-    const size_t fold = (size_t)(block / 64) * kReduceCols + 2;
-    return (sweep > fold ? sweep : fold) * sizeof(double);
+    const size_t words = (size_t)n_pad * (2 + (need_logv ? 1 : 0) + copies) + 2 * (size_t)gtab_n + block / 64;
+    return words * sizeof(double);
 }
 
 template <class Ops>
 static hipError_t set_lds_attr(size_t bytes)
 {
     hipError_t e;
-#define CFMM_SET(MAT, U, B)                                                                           \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, U, B>),             \
+#define CFMM_SET(MAT, B)                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, B>),                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                  \
     if (e != hipSuccess) return e;
-#define CFMM_SET_B(B)                                                                                 \
-    CFMM_SET(true, 1, B) CFMM_SET(true, 2, B) CFMM_SET(true, 4, B)                                    \
-    CFMM_SET(false, 1, B) CFMM_SET(false, 2, B) CFMM_SET(false, 4, B)
-    CFMM_SET_B(kSmallBlock) CFMM_SET_B(kMidBlock) CFMM_SET_B(kBigBlock)
-#undef CFMM_SET_B
+    CFMM_SET(true, kMidBlock) CFMM_SET(false, kMidBlock) CFMM_SET(true, kBigBlock) CFMM_SET(false, kBigBlock)
 #undef CFMM_SET
     return hipSuccess;
 }
@@ -1189,21 +1175,22 @@ static hipError_t set_lds_attr(size_t bytes)
 template <int B>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    dim3 g(c.grid + (ma.common.gflow ? 0 : ma.common.fold_blocks)), b(B);
-    if (ma.common.gflow) {
-        if (mat) launch_k(&sweep_multi<true, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-        else launch_k(&sweep_multi<false, B, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-    } else {
-        if (mat) launch_k(&sweep_multi<true, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-        else launch_k(&sweep_multi<false, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-    }
+    dim3 g(c.grid), b(B);
+    if (mat) launch_k(&sweep_multi<true, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+    else launch_k(&sweep_multi<false, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
 }
 
 hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (c.block == kBigBlock) launch_multi_b<kBigBlock>(ma, c, mat, s);
-    else if (c.block == kMidBlock) launch_multi_b<kMidBlock>(ma, c, mat, s);
-    else launch_multi_b<kSmallBlock>(ma, c, mat, s);
+    if (ma.common.gflow) {   // large-market mode: kMidBlock only
+        dim3 g(c.grid), b(kMidBlock);
+        if (mat) launch_k(&sweep_multi<true, kMidBlock, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        else launch_k(&sweep_multi<false, kMidBlock, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+    } else if (c.block == kBigBlock) {
+        launch_multi_b<kBigBlock>(ma, c, mat, s);
+    } else {
+        launch_multi_b<kMidBlock>(ma, c, mat, s);
+    }
     return hipGetLastError();
 }
 
@@ -1215,7 +1202,6 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);         \
     if (em != hipSuccess) return em;
     CFMM_SETM(true, kBigBlock) CFMM_SETM(false, kBigBlock) CFMM_SETM(true, kMidBlock) CFMM_SETM(false, kMidBlock)
-    CFMM_SETM(true, kSmallBlock) CFMM_SETM(false, kSmallBlock)
 #undef CFMM_SETM
     hipError_t e = set_lds_attr<ProductOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
@@ -1228,36 +1214,22 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     return set_lds_attr<UniV3Ops>(max_lds_bytes);
 }
 
-template <class Ops, int B>
-static void launch_block(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
-{
-    dim3 g(c.grid + (a.gflow ? 0 : a.fold_blocks)), b(B);
-    hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
-    if (a.gflow) { // large-market mode, one pool per lane per tile only
-        if (mat) launch_k(&sweep_kernel<Ops, true, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);
-        else launch_k(&sweep_kernel<Ops, false, 1, B, true>, g, b, c.lds_bytes, s, e0, e1, ops, a);
-        return;
-    }
-#define CFMM_GO(MAT, U) launch_k(&sweep_kernel<Ops, MAT, U, B, false>, g, b, c.lds_bytes, s, e0, e1, ops, a)
-    if (mat) {
-        if (c.unroll == 4) CFMM_GO(true, 4);
-        else if (c.unroll == 2) CFMM_GO(true, 2);
-        else CFMM_GO(true, 1);
-    } else {
-        if (c.unroll == 4) CFMM_GO(false, 4);
-        else if (c.unroll == 2) CFMM_GO(false, 2);
-        else CFMM_GO(false, 1);
-    }
-#undef CFMM_GO
-}
-
 template <class Ops>
 static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     if (a.m <= 0) return hipSuccess;
-    if (c.block == kBigBlock) launch_block<Ops, kBigBlock>(ops, a, c, mat, s);
-    else if (c.block == kMidBlock) launch_block<Ops, kMidBlock>(ops, a, c, mat, s);
-    else launch_block<Ops, kSmallBlock>(ops, a, c, mat, s);
+    dim3 g(c.grid);
+    hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
+    if (a.gflow) { // large-market mode: kMidBlock only
+        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, true>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kMidBlock, true>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+    } else if (c.block == kBigBlock) {
+        if (mat) launch_k(&sweep_kernel<Ops, true, kBigBlock, false>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kBigBlock, false>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
+    } else {
+        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kMidBlock, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+    }
     return hipGetLastError();
 }
 
@@ -1272,24 +1244,17 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (!p.deep) return launch_any(UniV3Ops{p}, a, c, mat, s);
+    if (!p.deep && !a.gflow) return launch_any(UniV3Ops{p}, a, c, mat, s);   // (large-market mode: cooperative variant only)
     UniV3CoopOps ops;
     ops.p = p;
     return launch_any(ops, a, c, mat, s);
 }
 
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
-                         hipEvent_t e0, hipEvent_t e1, unsigned* sync, unsigned long long* host_flag,
-                         unsigned long long host_seq, ArmWord arm)
+hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                         HostOut host, ArmWord arm)
 {
     dim3 g((n1 + kReduceCols - 1) / kReduceCols);
-    if (!sync) host_flag = nullptr;
-    if (block == kBigBlock)
-        launch_k(&reduce_partials<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
-    else if (block == kMidBlock)
-        launch_k(&reduce_partials<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
-    else
-        launch_k(&reduce_partials<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, sync, host_flag, host_seq, arm);
+    launch_k(&reduce_partials<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, out, host, arm);
     return hipGetLastError();
 }
 
@@ -1323,7 +1288,8 @@ __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, 
                                                        const double2* __restrict__ Delta,
                                                        const double2* __restrict__ Lambda,
                                                        const double2* __restrict__ Over, int compact,
-                                                       double2* __restrict__ Q, const double* __restrict__ eta, long long m)
+                                                       double2* __restrict__ Q, const double* __restrict__ eta, long long m,
+                                                       int* __restrict__ left_window)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
@@ -1333,6 +1299,9 @@ __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, 
     read_trade(Delta, Lambda, Over, compact, i, d, l);
     const double2 rn = make_double2((r.x + g * d.x) - l.x, (r.y + g * d.y) - l.y);
     R[i] = rn;
+    // a reserve that leaves the operand window of the fast arithmetic (sweep.h kFastExp) sends the segment back to the
+    // compiler's division / square-root sequences
+    if (left_window && !(in_fast_window(rn.x) && in_fast_window(rn.y))) *left_window = 1;
     if (Q) {
         const double e = eta[i], lg = log(g), le = log(e), l1 = log(rn.x), l2 = log(rn.y);
         Q[i] = make_double2(((lg + le) + l2) + e * l1, e * ((lg + l1) - le) + l2);
@@ -1340,11 +1309,12 @@ __global__ __launch_bounds__(256) void update_two_coin(double2* __restrict__ R, 
 }
 
 hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2* Delta, const double2* Lambda,
-                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, hipStream_t s)
+                                  const double2* Over, int compact, double2* Q, const double* eta, int64_t m, int* left_window,
+                                  hipStream_t s)
 {
     if (m <= 0) return hipSuccess;
     hipLaunchKernelGGL(update_two_coin, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, R, gamma, Delta, Lambda, Over,
-                       compact, Q, eta, (long long)m);
+                       compact, Q, eta, (long long)m, left_window);
     return hipGetLastError();
 }
 
@@ -1369,13 +1339,11 @@ hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const do
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, int block,
-                                const PeerSet& ps, hipEvent_t e0, hipEvent_t e1)
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, const PeerSet& ps,
+                                hipEvent_t e0, hipEvent_t e1)
 {
     dim3 g((n1 + kReduceCols - 1) / kReduceCols);
-    if (block == kBigBlock) launch_k(&reduce_gather<kBigBlock>, g, dim3(kBigBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
-    else if (block == kMidBlock) launch_k(&reduce_gather<kMidBlock>, g, dim3(kMidBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
-    else launch_k(&reduce_gather<kSmallBlock>, g, dim3(kSmallBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
+    launch_k(&reduce_gather<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
     return hipGetLastError();
 }
 

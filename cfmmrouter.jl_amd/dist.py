@@ -21,140 +21,81 @@ from .cfmms import PoolBatch
 from .router import DeviceBackend, Router, _segments_of
 
 
-class PeerAllReduce:
-    """One-shot all-reduce(sum) of {Ψ, acc} over xGMI peer mappings (csrc/peer_allreduce.hip).
-
-    The buffers are a torch.distributed._symmetric_memory allocation (torch does the IPC handle
-    exchange); the kernel is ours.  `slot()` is where this step's local {Ψ, acc} must be written
-    (cfmm_sweep_dev targets it directly), `reduce(out)` then leaves the rank-ordered sum in `out` on
-    every rank.  `PeerAllReduce.create` returns None whenever anything about the fast path is not
-    available or does not reproduce RCCL's result on a self-test -- callers then use dist.all_reduce."""
-
-    def __init__(self, count, group, device):
-        import ctypes as C
-
-        import torch
-        import torch.distributed as dist
-        import torch.distributed._symmetric_memory as symm_mem
-
-        from ._lib import lib
-
-        self._torch, self._C, self._lib = torch, C, lib()
-        self.count = int(count)
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        # [2][count] doubles + 2 uint64 flags (this class's kernel) + [2][count][2] granules (cfmm_set_peers)
-        words = 6 * self.count + 2
-        self.buf = symm_mem.empty(words, dtype=torch.float64, device=device)
-        self.buf.zero_()
-        gname = (group or dist.group.WORLD).group_name
-        self.hdl = symm_mem.rendezvous(self.buf, gname)
-        ptrs = [int(p) for p in self.hdl.buffer_ptrs]
-        if len(ptrs) != self.world:
-            raise RuntimeError("symmetric memory returned an unexpected number of peers")
-        self._ptrs = (C.c_uint64 * self.world)(*ptrs)
-        self.seq = 0
-        torch.cuda.synchronize(device)
-        dist.barrier(group=group)                        # everybody's flags are zero before step 1 (plain RCCL
-        torch.cuda.synchronize(device)                   # barrier: nothing here may spin on a peer mapping)
-
-    def slot(self):
-        """Device view [count] that the NEXT reduce() will read as this rank's contribution."""
-        parity = (self.seq + 1) & 1
-        return self.buf[parity * self.count:(parity + 1) * self.count]
-
-    def reduce(self, out):
-        self.seq += 1
-        stream = self._torch.cuda.current_stream().cuda_stream
-        rc = self._lib.cfmm_peer_allreduce(self._C.c_void_p(stream), self._ptrs, self.world, self.rank, self.count,
-                                           self._C.c_uint64(self.seq), self._C.c_void_p(out.data_ptr()))
-        if rc != 0:
-            raise RuntimeError("cfmm_peer_allreduce launch failed")
-
-    @staticmethod
-    def create(count, group, device, checks=4):
-        import torch
-        import torch.distributed as dist
-        try:
-            par = PeerAllReduce(count, group, device)
-            good = True
-            out = torch.empty(count, dtype=torch.float64, device=device)
-            for k in range(checks):   # self-test against RCCL before trusting the fast path
-                g = torch.Generator(device="cpu").manual_seed(1000 * k + par.rank)
-                x = torch.rand(count, dtype=torch.float64, generator=g).to(device) * (10.0 ** k)
-                par.slot().copy_(x)
-                par.reduce(out)
-                ref = x.clone()
-                dist.all_reduce(ref, group=group)
-                torch.cuda.synchronize(device)
-                scale = float(ref.abs().max())
-                good = good and bool(torch.isfinite(out).all()) and float((out - ref).abs().max()) <= 1e-12 * scale
-        except Exception:
-            par, good = None, False
-        flag = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)   # all ranks or none
-        return par if float(flag.item()) == 1.0 else None
-
-
 class IpcPeers:
     """The symmetric buffers of cfmm_set_peers through the LIBRARY's own IPC export
     (cfmm_peer_buffer_alloc / _open: hipIpcGetMemHandle / hipIpcOpenMemHandle) -- no private torch
     API; torch.distributed only carries the 64-byte handles (any launcher's channel would do).
-    `ptrs[p]` is rank p's buffer mapped into this process (own rank: the allocation itself)."""
+    `ptrs[p]` is rank p's buffer mapped into this process (own rank: the allocation itself).
+
+    Every rank takes part in every collective of the set-up whatever its local outcome (a rank that
+    fails locally must not walk into the next collective while the others are still in this one):
+    `ok` tells whether THIS rank has all mappings; open_peer_buffers votes on it."""
 
     def __init__(self, ctx, group):
         import torch.distributed as dist
 
         self.ctx, self.group = ctx, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.own, handle = ctx.peer_buffer_alloc()
+        self.own, self.ptrs, self.ok = None, [], True
+        handle = None
+        try:
+            self.own, handle = ctx.peer_buffer_alloc()
+        except Exception:
+            self.ok = False
         handles = [None] * self.world
-        dist.all_gather_object(handles, handle, group=group)
-        self.ptrs = [self.own if p == self.rank else ctx.peer_buffer_open(handles[p]) for p in range(self.world)]
-        dist.barrier(group=group)       # every rank has mapped every buffer before anybody writes
+        dist.all_gather_object(handles, handle, group=group)     # a failed rank contributes None
+        if self.ok and all(h is not None for h in handles):
+            try:
+                for p in range(self.world):
+                    self.ptrs.append(self.own if p == self.rank else ctx.peer_buffer_open(handles[p]))
+            except Exception:
+                self.ok = False
+        else:
+            self.ok = False
+        dist.barrier(group=group)       # every rank has mapped every buffer (or given up) before anybody writes
 
-    def close(self):
+    def close(self, collective=True):
+        """Unmap the peers' buffers and free the own one.  collective=True: all ranks call this together."""
         import torch.distributed as dist
         try:
             self.ctx.set_peers([], 0, 0, 0)
-            for p, ptr_ in enumerate(self.ptrs):
-                if p != self.rank:
-                    self.ctx.peer_buffer_close(ptr_)
-            dist.barrier(group=self.group)   # nobody still maps the buffer that is about to be freed
-            self.ctx.peer_buffer_free(self.own)
         except Exception:
             pass
+        for p, ptr_ in enumerate(self.ptrs):
+            if p != self.rank:
+                try:
+                    self.ctx.peer_buffer_close(ptr_)
+                except Exception:
+                    pass
         self.ptrs = []
+        if collective:
+            try:
+                dist.barrier(group=self.group)   # nobody still maps the buffer that is about to be freed
+            except Exception:
+                pass
+        if self.own is not None:
+            try:
+                self.ctx.peer_buffer_free(self.own)
+            except Exception:
+                pass
+            self.own = None
 
 
 def open_peer_buffers(ctx, group, device):
-    """Symmetric buffers for `ctx` on every rank of `group`, or None on ALL ranks (collective vote):
-    first the library's own IPC export, then torch's symmetric memory (nccl groups only).
-    Returns an object with `.ptrs` (and `.close()` for the IPC flavour)."""
+    """Symmetric buffers for `ctx` on every rank of `group` through the library's IPC export, or None on ALL
+    ranks (collective vote) -- callers then all-reduce through torch.distributed (RCCL).
+    Returns an object with `.ptrs` and `.close()`."""
     import torch
     import torch.distributed as dist
 
-    def vote(ok):
-        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64,
-                         device=device if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        return float(t.item()) == 1.0
-
-    peers = None
-    try:
-        peers = IpcPeers(ctx, group)
-    except Exception:
-        peers = None
-    if vote(peers is not None):
+    peers = IpcPeers(ctx, group)          # takes part in all its collectives even when it fails locally
+    t = torch.tensor([1.0 if peers.ok else 0.0], dtype=torch.float64,
+                     device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    if float(t.item()) == 1.0:
         return peers
-    if peers is not None:
-        peers.close()
-    if dist.get_backend(group) != "nccl":
-        return None
-    sym = PeerAllReduce.create(ctx.n_tokens + 1, group, device)   # votes internally
-    if sym is None:
-        return None
-    sym.ptrs = [int(p) for p in sym.hdl.buffer_ptrs]
-    return sym
+    peers.close(collective=True)          # every rank is here: the barrier inside is matched
+    return None
 
 
 def shard_range(m: int, rank: int, world: int):

@@ -80,39 +80,45 @@ const char* cfmm_version(void);
 int cfmm_set_stream(cfmm_ctx* ctx, void* hip_stream);
 int cfmm_reset_stream(cfmm_ctx* ctx);
 
-/* Tuning / instrumentation knobs (0 = automatic choice): "block" (256 | 512 | 1024 threads),
- * "max_grid", "unroll" (1|2|4 pools per lane per tile), "bin_copies" (1 = one LDS netflow copy
- * per block, 2 = one per wavefront), "time_kernels", "nt_stores" (trade stores: 0 plain, 1 non-temporal, 2 write-through = default), "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool
- * walks only, 1 wavefront-cooperative deep walks; per-segment launches only -- a fused multi-family launch always runs the
- * cooperative variant, which computes the same bits), "spin_wait" (default 0; 1 = host-pointer calls busy-poll the stream),
- * "host_flag" (default 1: a zero-copy host-pointer sweep ends when the last fold block raises a flag in mapped host memory,
- * which the caller polls, instead of on the stream's completion signal), "host_granules" (default 1: such a sweep delivers {psi, acc} as self-validating 8-byte granules that the
- * library re-reads until complete, instead of outputs + flag word; same values), "inline_fold" (default 0; 1 = the partial rows are
- * folded by extra blocks of the sweep launch instead of by a second launch -- same bits, measured slower), "multi_threads"
- * (multi-device contexts, see cfmm_ctx_create_multi), "zero_copy" (default 1: host-pointer calls
- * exchange v / Psi through mapped pinned memory instead of copy commands), "fuse_segments" (default 1: all
- * pool families swept by one launch; 0: one launch per segment), "geomean_exact" (1 = evaluate
- * GeometricMeanTwoCoin with pow in the reference's operation order instead of the default
- * log-space form; both are within 1e-12 of the reference), "xcd_map" (fused launches: 1 = default, XCD-aware
- * block -> segment map weighted by pools x cost per pool; 2 = XCD-aware with equal cost per pool; 0 = block b ->
- * segment b % nseg), "cost_geomean" / "cost_univ3" (cost of one evaluation in tenths of a ProductTwoCoin one, used
- * by that map; defaults 10 / 10 = blocks in proportion to pool counts), "wave_split" (default 0; 1 = every block of a fused launch sweeps every segment,
- * its wavefronts dealt to the families), "alternate" (default 1: consecutive sweeps walk every lane's tiles in
- * alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's L2 -- two sweeps
- * at the same v then agree to summation-order rounding (trades: bit for bit), every second one bit for bit; 0: always
- * forwards, every sweep bit-identical), "pack" (default 1: sweeps read an 8-byte {token pair, fee-table index} record
- * instead of gamma + Ai when a launch's distinct fees fit a 256-entry table; same results), "compact_trades" (default 1:
- * a materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2, Lambda1}, a two-coin trade has
- * one direction -- plus overflow rows for pools whose four values do not fit that form; cfmm_get_trades* decode it and
- * cfmm_trades_dev expands it, bit for bit the rows of the 0 setting = separate Delta / Lambda rows), "armed" (default 1:
- * cfmm_route enqueues evaluation k+1 while evaluation k runs; its blocks wait on the device -- bounded by
- * "arm_timeout_ms", default 2000 -- until the host has written the next price vector straight into device memory
- * through the PCIe BAR, which takes the launch latency off the critical path of every evaluation; needs a large-BAR
- * system, otherwise -- or with CFMM_AMD_ARMED=0 in the environment -- the evaluations are launched when their prices
- * are ready; identical results either way).  Unknown keys are
- * CFMM_ERR_INVALID_ARG.  Environment: HIP_FORCE_DEV_KERNARG
- * is set to 1 when the library is loaded unless already set (kernel arguments in device memory: -10 % per step);
- * CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */
+/* Options (int64 values; unknown keys are CFMM_ERR_INVALID_ARG).  Results never depend on the tuning knobs beyond
+ * summation-order rounding of psi / acc; trades are bit-identical under all of them.
+ *   launch geometry   "block" (0 = auto | 512 | 1024 threads), "max_grid" (0 = auto), "bin_copies" (0 = auto, 1 = one
+ *                     LDS netflow copy per block, 2 = one per wavefront), "fuse_segments" (default 1: all pool families
+ *                     swept by one launch; 0: one launch per segment), "cost_geomean" / "cost_univ3" (cost of one
+ *                     evaluation in tenths of a ProductTwoCoin one: how a fused launch divides its blocks; 10 / 10),
+ *                     "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool walks only, 1 wavefront-cooperative
+ *                     deep walks; per-segment launches only -- a fused launch always runs the cooperative variant)
+ *   data layout       "pack" (default 1: sweeps read an 8-byte {token pair, fee-table index} record instead of gamma +
+ *                     Ai when a launch's distinct fees fit a 256-entry table), "compact_trades" (default 1: a
+ *                     materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2,
+ *                     Lambda1}, a two-coin trade has one direction -- plus overflow rows for pools whose four values
+ *                     do not fit that form; cfmm_get_trades* / cfmm_trades_dev return the reference's rows bit for bit)
+ *   arithmetic        "fast_math" (default 1: where every operand lies in [2^-150, 2^150] -- pool constants checked at
+ *                     upload, prices by every block as it stages them -- divisions and square roots run the compiler's
+ *                     own correctly-rounded instruction sequences WITHOUT their range scaffolding, and divisions by a
+ *                     price or a fee reuse a reciprocal refined once per token / fee tier: same bits, ~half the
+ *                     instructions; 0: the compiler's sequences everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
+ *                     with pow in the reference's operation order instead of the default log-space form; both are within
+ *                     1e-12 of the reference), "alternate" (default 1: consecutive sweeps walk every lane's tiles in
+ *                     alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's
+ *                     L2 -- two sweeps at the same v then agree to summation-order rounding (trades: bit for bit), every
+ *                     second one bit for bit; 0: always forwards, every sweep bit-identical)
+ *   host boundary     "zero_copy" (default 1: host-pointer calls read v through mapped pinned memory), "host_flag"
+ *                     (default 1: such a call ends when {psi, acc} have arrived in pinned host memory as self-validating
+ *                     8-byte granules, which the library polls, instead of on the stream's completion signal),
+ *                     "time_kernels" (see cfmm_kernel_times), "multi_threads" (multi-device contexts)
+ *   route!            "armed" (default 1: cfmm_route enqueues evaluation k+1 while evaluation k runs; its blocks wait on
+ *                     the device -- bounded by "arm_timeout_ms", default 2000 -- until the host has written the next price
+ *                     vector straight into device memory through the PCIe BAR, which takes the launch latency off the
+ *                     critical path of every evaluation; needs a large-BAR system, otherwise -- or with CFMM_AMD_ARMED=0
+ *                     in the environment -- the evaluations are launched when their prices are ready; identical results
+ *                     either way; also on cfmm_set_peers contexts and on multi-device contexts whose shards sit on
+ *                     distinct devices), "stop_in_noise" (default 0 = the stopping rules of L-BFGS-B 3.0, the
+ *                     reference's solver; 1 = additionally end the run when a line-search trial point differs from the
+ *                     current dual value by no more than the factr tolerance: fewer evaluations, v* up to a decade
+ *                     further from the reference's).
+ * Environment: HIP_FORCE_DEV_KERNARG is set to 1 when the library is loaded unless already set (kernel arguments in
+ * device memory: -10 % per step); CFMM_AMD_PEER_TIMEOUT_S (see cfmm_set_peers). */
 int cfmm_set_option(cfmm_ctx* ctx, const char* key, int64_t value);
 int cfmm_get_option(const cfmm_ctx* ctx, const char* key, int64_t* value);
 
@@ -203,21 +209,7 @@ int cfmm_trades_dev(cfmm_ctx* ctx, const double** d_delta, const double** d_lamb
 int cfmm_kernel_times(cfmm_ctx* ctx, int64_t* sweep_launches, double* sweep_ms,
                       int64_t* reduce_launches, double* reduce_ms);
 
-/* ---- sharded runs: low-latency all-reduce of {psi, acc} over xGMI peer mappings ------------ */
-
-/* One-shot all-reduce(sum) of `count` doubles across the `world` GPUs of one node.  peer_buffers[p]
- * is the device address, mapped into THIS process, of rank p's symmetric buffer laid out as
- * [2][count] doubles followed by 2 uint64 flags (+ the granules of cfmm_set_peers, unused here),
- * zero-initialised before first use (e.g. a torch.distributed._symmetric_memory allocation:
- * hdl.buffer_ptrs).  Before the call, this rank's
- * contribution must have been written (on the same stream) to its own buffer at
- * [seq & 1][0..count) -- cfmm_sweep_dev can target it directly.  seq starts at 1 and increases by
- * one per call on every rank.  Every rank sums the peers in rank order, so all ranks obtain
- * bit-identical results.  Asynchronous on hip_stream; if a peer does not publish within
- * CFMM_AMD_PEER_TIMEOUT_S seconds (default 30) the output is filled with NaN instead of hanging.  Replaces nothing in the reference
- * (it has no distributed path); it is the collective of SURVEY 8e. */
-int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t world, int32_t rank,
-                        int64_t count, uint64_t seq, double* d_out);
+/* ---- sharded runs: the all-reduce of {psi, acc} over xGMI peer mappings, inside the fold launch -- */
 
 /* Sharded operation of a context (one process per GPU): after this call EVERY sweep of the context --
  * cfmm_find_arb, cfmm_eval, cfmm_route, and cfmm_sweep_dev -- returns the psi / acc of the WHOLE
@@ -226,9 +218,10 @@ int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t 
  * self-validating 8-byte granules {sequence tag, 32 payload bits} in this rank's buffer -- no flag, no
  * fence -- and adds the same columns of every peer in rank order: every rank obtains bit-identical
  * results).  Buffer layout, per rank, with count = n_tokens + 1, zero-initialised before first use:
- *     [2][count] doubles | 2 uint64 (data + flags of cfmm_peer_allreduce) | [2][count][2] uint64 granules
- * i.e. (6 * count + 2) 8-byte words (e.g. a torch.distributed._symmetric_memory allocation;
- * peer_buffers[p] = address of rank p's buffer mapped into THIS process).  Every rank
+ *     [2][count][2] uint64 granules  =  cfmm_peer_buffer_bytes(n_tokens) bytes
+ * (peer_buffers[p] = address of rank p's buffer mapped into THIS process; cfmm_peer_buffer_alloc / _open below, or any
+ * other symmetric allocation).  It replaces nothing in the reference (which has no distributed path): it is the
+ * collective of SURVEY 8e.  Every rank
  * must issue the same sequence of sweeps (route! does: all ranks take bit-identical L-BFGS-B steps).
  * seq = number of sharded sweeps already performed on these buffers (0 for fresh ones).  A rank
  * waits up to CFMM_AMD_PEER_TIMEOUT_S seconds (environment, default 30) for a peer, then the output
@@ -236,12 +229,13 @@ int cfmm_peer_allreduce(void* hip_stream, const uint64_t* peer_buffers, int32_t 
 int cfmm_set_peers(cfmm_ctx* ctx, const uint64_t* peer_buffers, int32_t world, int32_t rank, uint64_t seq);
 
 /* The symmetric buffers of cfmm_set_peers without any framework: every rank allocates its buffer
- * (sized and zeroed for the context's n_tokens), publishes the 64-byte IPC handle through whatever channel
+ * (fine-grained device memory, sized and zeroed for the context's n_tokens), publishes the 64-byte IPC handle through whatever channel
  * its launcher has (MPI, torch.distributed, a file), and maps the other ranks' buffers from their handles
  * (hipIpcGetMemHandle / hipIpcOpenMemHandle; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver stack).
  * The pointers go to cfmm_set_peers (own rank: the pointer from _alloc).  _close unmaps a peer's buffer,
  * _free releases the own one (after every peer has closed it). */
 #define CFMM_IPC_HANDLE_BYTES 64
+int64_t cfmm_peer_buffer_bytes(int32_t n_tokens);
 int cfmm_peer_buffer_alloc(cfmm_ctx* ctx, uint64_t* d_buf, unsigned char handle[CFMM_IPC_HANDLE_BYTES]);
 int cfmm_peer_buffer_open(cfmm_ctx* ctx, const unsigned char handle[CFMM_IPC_HANDLE_BYTES], uint64_t* d_peer);
 int cfmm_peer_buffer_close(cfmm_ctx* ctx, uint64_t d_peer);
@@ -287,7 +281,7 @@ int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double
 /* Number of segments and their description (kind, pool count, launch geometry). */
 int32_t cfmm_segment_count(const cfmm_ctx* ctx);
 int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* block,
-                      int32_t* grid, int32_t* unroll);
+                      int32_t* grid);
 
 #ifdef __cplusplus
 }

@@ -11,4 +11,4 @@ else:
     r = d["roofline"]
     print(name, "%.3e pools/s" % d["value"], "ms/step %.4f" % d["ms_per_step"],
           "sweep_ms %.4f reduce_ms %.4f frac %.3f" % (r["kernel_ms"], r["reduce_kernel_ms"], r["frac"]),
-          [(s["block"], s["grid"], s["unroll"]) for s in d["config"]["segments"]])
+          [(s["block"], s["grid"]) for s in d["config"]["segments"]])

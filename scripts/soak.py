@@ -1,6 +1,6 @@
 """Soak test of the host <-> device hand-overs that are on by default (pre-armed route! evaluations through the PCIe
 BAR, output granules): many thousand evaluations, every result compared bit for bit with a context that uses the plain
-paths (armed = 0, host_granules = 0), every call bounded in time.  usage: python scripts/soak.py [seconds]"""
+paths (armed = 0, host_flag = 0), every call bounded in time.  usage: python scripts/soak.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 n = 96
 batches = [synth.product_pools(40_000, n, seed=1), synth.geomean_pools(20_000, n, seed=2), synth.bounded_product_pools(15_000, n, seed=3)]
 a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
-b.ctx.set_option("armed", 0); b.ctx.set_option("host_granules", 0)
+b.ctx.set_option("armed", 0); b.ctx.set_option("host_flag", 0)
 for be in (a, b):
     be.ctx.set_option("alternate", 0)      # identical summation order on every sweep
 rng = np.random.default_rng(5)

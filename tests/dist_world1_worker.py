@@ -1,7 +1,7 @@
 """Run under `python -m torch.distributed.run --nproc-per-node 1` on the MI355X box by
 tests/test_gpu_dist.py: the multi-process sharded paths of cfmmrouter.jl_amd/dist.py at world = 1 --
-real RCCL ("nccl") process group, real symmetric-memory allocation, the one-shot peer all-reduce
-kernel, cfmm_set_peers -- each compared with the unsharded router.  Prints one JSON line."""
+real RCCL ("nccl") process group, the library's IPC peer buffers, cfmm_set_peers (fold + gather in one
+launch, pre-armed route!) and the RCCL fall-back -- each compared with the unsharded router.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -23,21 +23,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
 dev = torch.device("cuda", lr)
 out = {"world": dist.get_world_size(), "backend": dist.get_backend()}
 
-# (a) the peer all-reduce kernel on a symmetric-memory allocation
-par = crd.PeerAllReduce.create(513, None, dev)
-out["peer_available"] = par is not None
-if par is not None:
-    res = torch.empty(513, dtype=torch.float64, device=dev)
-    ok = True
-    for k in range(50):   # sequence parity, flag reuse
-        x = torch.rand(513, dtype=torch.float64, device=dev) * (k + 1)
-        par.slot().copy_(x)
-        par.reduce(res)
-        torch.cuda.synchronize()
-        ok = ok and bool(torch.equal(res, x))
-    out["peer_50_reduces_exact"] = ok
-
-# (b) / (c) sharded routers: in-library peer path, then RCCL all-reduce driven from Python
+# sharded routers: in-library peer path, then RCCL all-reduce driven from Python
 n = 512
 market = [synth.product_pools(120_000, n, seed=1), synth.geomean_pools(30_000, n, seed=2)]
 obj = cr.LinearNonnegative(synth.linear_prices(n, seed=1))

@@ -21,7 +21,7 @@ world = int(sys.argv[1])
 n = 512
 market = [synth.product_pools(240_000, n, seed=71), synth.geomean_pools(80_000, n, seed=72)]
 count = n + 1
-bufs = [torch.zeros(6 * count + 2, dtype=torch.float64, device="cuda") for _ in range(world)]
+bufs = [torch.zeros(4 * count, dtype=torch.float64, device="cuda") for _ in range(world)]   # cfmm_peer_buffer_bytes
 ptrs = [b.data_ptr() for b in bufs]
 ranks = [cr.DeviceBackend(n, shard_batches(market, r, world)) for r in range(world)]
 for be in ranks:

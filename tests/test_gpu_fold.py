@@ -1,11 +1,8 @@
-"""GPU tests of the in-launch row fold (option "inline_fold") and the host-visible completion flag
-(option "host_flag"): the partial rows of a sweep are published with write-through stores and
-folded by extra blocks of the SAME launch (src/router.jl:81-83, :98-100 summed over blocks).
-
-The separate-launch fold (reduce_partials) sums the rows in exactly the same order, so the two
-forms must agree BIT FOR BIT; a stale or torn row read inside the launch shows up as a mismatch.
-Per MI355X_MICROARCH.md the hand-off is exercised back to back (the fold blocks' caches are warm
-with the previous sweep's rows), with different prices per sweep and with uneven per-block load.
+"""GPU tests of the launch forms of one evaluation: the row fold and its host-visible outputs (self-validating
+granules, option "host_flag"), fused multi-family launches under their block -> segment maps, empty segments,
+the determinism claim, alternating tile directions, packed fee + token records, compact trade records, and the
+fast arithmetic (option "fast_math": division / square root without range scaffolding) -- every variant must
+produce the bits of the plain form (src/router.jl:81-83, :98-100 summed over blocks; src/cfmms.jl:125-140).
 """
 import numpy as np
 import pytest
@@ -17,119 +14,13 @@ from helpers import oracle_sweep, rel_to_max
 pytestmark = pytest.mark.gpu
 
 
-def _pair(n, batches, mode=1, **opts):
-    a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
-    a.ctx.set_option("inline_fold", mode)
-    b.ctx.set_option("inline_fold", 0)
-    for k, v in opts.items():
-        a.ctx.set_option(k, v)
-        b.ctx.set_option(k, v)
-    return a, b
-
-
-@pytest.mark.parametrize("shape", ["config2", "config3mini", "config4mini", "bounded", "tiny", "n1024"])
-def test_inline_fold_bitwise_equals_separate_fold(shape):
-    if shape == "config2":
-        n, batches = 64, [synth.product_pools(100_000, 64, seed=3)]
-    elif shape == "config3mini":
-        n, batches = 256, [synth.product_pools(200_000, 256, seed=3), synth.geomean_pools(150_001, 256, seed=4)]
-    elif shape == "config4mini":
-        n, batches = 512, [synth.product_pools(500_000, 512, seed=5)]
-    elif shape == "bounded":
-        n, batches = 256, [synth.bounded_product_pools(120_000, 256, seed=6)]
-    elif shape == "tiny":
-        n, batches = 2, [synth.product_pools(3, 2, seed=7)]
-    else:
-        n, batches = 1024, [synth.product_pools(70_000, 1024, seed=8)]
-    a, b = _pair(n, batches)
-    try:
-        rng = np.random.default_rng(11)
-        for it in range(40):   # back to back: the fold blocks re-read row addresses they read one sweep ago
-            v = synth.sweep_prices(n, seed=100 + it) * rng.uniform(0.5, 2.0)
-            for mat in (False, True):
-                pa = (a.find_arb if mat else a.eval)(v)
-                pb = (b.find_arb if mat else b.eval)(v)
-                if shape == "n1024":   # one LDS bin copy shared by the wavefronts: the sum order is not fixed
-                    assert rel_to_max(pa[0], pb[0]) <= 1e-14 and abs(pa[1] - pb[1]) <= 1e-12 * abs(pb[1])
-                else:
-                    np.testing.assert_array_equal(pa[0], pb[0])
-                    assert pa[1] == pb[1]
-        D, L, psi, acc = oracle_sweep(batches, n, v)
-        assert rel_to_max(pa[0], psi) <= 1e-12
-        Da, La = a.trades()
-        if shape != "config3mini":   # geomean trades differ from the oracle by a few ulp (tested elsewhere)
-            np.testing.assert_array_equal(Da, D)
-            np.testing.assert_array_equal(La, L)
-    finally:
-        a.close()
-        b.close()
-
-
-def test_inline_fold_under_uneven_load():
-    """A deep-walk UniV3 segment next to a ProductTwoCoin segment: blocks of one launch finish at very
-    different times, and a second context streams on another stream meanwhile."""
-    n = 128
-    batches = [synth.product_pools(300_000, n, seed=21), synth.univ3_pools(40_000, n, 40, seed=22)]
-    a, b = _pair(n, batches)
-    noise = cr.DeviceBackend(256, [synth.product_pools(1_000_000, 256, seed=23)])
-    try:
-        import torch
-        vt = torch.from_numpy(synth.sweep_prices(256, seed=1)).cuda()
-        ot = torch.zeros(257, dtype=torch.float64, device="cuda")
-        for it in range(25):
-            for _ in range(4):   # asynchronous streaming load on the context's own stream
-                noise.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
-            v = synth.sweep_prices(n, seed=300 + it)
-            pa, pb = a.eval(v), b.eval(v)
-            np.testing.assert_array_equal(pa[0], pb[0])
-            assert pa[1] == pb[1]
-        torch.cuda.synchronize()
-    finally:
-        a.close()
-        b.close()
-        noise.close()
-
-
-def test_device_resident_sweeps_with_inline_fold():
-    """cfmm_sweep_dev (the bench's timed path): many launches in flight on one stream, each leaving the
-    arrival counters zero for the next."""
-    import torch
-    n = 256
-    batches = [synth.product_pools(500_000, n, seed=31), synth.geomean_pools(500_000, n, seed=32)]
-    a, b = _pair(n, batches)
-    try:
-        st = torch.cuda.Stream()
-        a.ctx.set_stream(st.cuda_stream)
-        b.ctx.set_stream(st.cuda_stream)
-        vs = [torch.from_numpy(synth.sweep_prices(n, seed=400 + k)).cuda() for k in range(8)]
-        oa = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in vs]
-        ob = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in vs]
-        torch.cuda.synchronize()
-        for rep in range(6):
-            for k, vt in enumerate(vs):
-                a.ctx.sweep_dev(vt.data_ptr(), oa[k].data_ptr(), rep % 2 == 0)
-            for k, vt in enumerate(vs):
-                b.ctx.sweep_dev(vt.data_ptr(), ob[k].data_ptr(), rep % 2 == 0)
-            st.synchronize()
-            for k in range(len(vs)):
-                assert torch.equal(oa[k], ob[k])
-        a.ctx.reset_stream()
-        b.ctx.reset_stream()
-    finally:
-        a.close()
-        b.close()
-
-
-@pytest.mark.parametrize("inline", [0, 1])
-def test_host_flag_and_stream_wait_agree(inline):
-    """Zero-copy host-pointer sweeps end when the last fold block raises a flag in mapped host memory
-    (option "host_flag", default on); waiting for the stream instead must give the same bits."""
+def test_host_flag_and_stream_wait_agree():
+    """Zero-copy host-pointer sweeps end when {Ψ, acc} have arrived in mapped host memory as self-validating
+    granules (option "host_flag", default on); waiting for the stream + a D2H copy instead must give the same bits."""
     n = 256
     batches = [synth.product_pools(250_000, n, seed=41), synth.geomean_pools(250_000, n, seed=42)]
     a = cr.DeviceBackend(n, batches)
     b = cr.DeviceBackend(n, batches)
-    a.ctx.set_option("inline_fold", inline)
-    b.ctx.set_option("inline_fold", inline)
     b.ctx.set_option("host_flag", 0)
     try:
         assert a.ctx.get_option("host_flag") == 1
@@ -153,10 +44,9 @@ def test_host_flag_and_stream_wait_agree(inline):
 def test_empty_segment_through_the_abi_is_ignored():
     """an m == 0 batch added through the C ABI must not leave an unwritten partial row."""
     n = 16
-    for fuse, inline in ((0, 0), (0, 1), (1, 1)):
+    for fuse in (0, 1):
         be = cr.DeviceBackend(n, [])
         be.ctx.set_option("fuse_segments", fuse)
-        be.ctx.set_option("inline_fold", inline)
         try:
             pb = synth.product_pools(1000, n, seed=51)
             empty = pb.slice(0, 0)
@@ -175,11 +65,11 @@ def test_empty_segment_through_the_abi_is_ignored():
             be.close()
 
 
-@pytest.mark.parametrize("opts", [dict(xcd_map=0), dict(xcd_map=1), dict(wave_split=1), dict(wave_split=1, inline_fold=1)])
+@pytest.mark.parametrize("opts", [dict(), dict(max_grid=200), dict(fast_math=0), dict(block=1024)])
 @pytest.mark.parametrize("families", ["pg", "pgu", "pgup"])
 def test_fused_launch_block_maps_agree_with_oracle(opts, families):
-    """The fused multi-family launch under its block -> segment maps (plain b % nseg, XCD-aware, wavefronts
-    dealt to the families): same trades bit for bit, same Ψ to summation-order rounding."""
+    """The fused multi-family launch under its block -> segment maps (XCD-aware when the grid is a multiple of 256
+    blocks, plain b % nseg otherwise -- max_grid=200): same trades bit for bit, same Ψ to summation-order rounding."""
     n = 200
     batches = [synth.product_pools(300_000, n, seed=61), synth.geomean_pools(200_001, n, seed=62)]
     if "u" in families:
@@ -333,16 +223,14 @@ def test_compact_trade_records_are_lossless():
 
 
 @pytest.mark.parametrize("n", [2, 7, 8, 64, 257, 1000])
-def test_output_granules_equal_flagged_outputs(n):
-    """Option "host_granules" (default 1): a host-pointer sweep returns {Ψ, acc} as self-validating 8-byte granules
-    (sequence tag + half of a double, 16 per fold block = two full 64-byte lines per store instruction) that the host
-    re-reads until all carry the tag, instead of outputs + drain + ticket + flag word.  Same values, any n_tokens
-    (the last fold block pads its lines with zero columns)."""
+def test_output_granules_equal_copied_outputs(n):
+    """A host-pointer sweep returns {Ψ, acc} as self-validating 8-byte granules (sequence tag + half of a double, 16 per
+    fold block = two full 64-byte lines per store instruction) that the host re-reads until all carry the tag.  Same
+    values as d_out + a D2H copy (zero_copy = 0), any n_tokens (the last fold block pads its lines with zero columns)."""
     m = 40_000 if n > 2 else 300
     batches = [synth.product_pools(m, n, seed=n)] + ([synth.geomean_pools(m // 2, n, seed=n + 1)] if n > 2 else [])
     a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
-    a.ctx.set_option("host_granules", 1)
-    b.ctx.set_option("host_granules", 0)
+    b.ctx.set_option("zero_copy", 0)
     try:
         for it in range(25):
             v = synth.sweep_prices(n, seed=300 + it)
@@ -357,3 +245,73 @@ def test_output_granules_equal_flagged_outputs(n):
     finally:
         a.close()
         b.close()
+
+
+def _wide_market(n, seed, scale_exp):
+    """Product / GeoMean / UniV3 pools whose reserves, liquidity and prices are scaled by 2^scale_exp."""
+    bp, bg = synth.product_pools(60_000, n, seed=seed), synth.geomean_pools(30_000, n, seed=seed + 1)
+    bu = synth.univ3_pools(10_000, n, 6, seed=seed + 2)
+    f = 2.0 ** scale_exp
+    bp.R *= f
+    bg.R *= f
+    bu.liquidity *= f
+    return [bp, bg, bu]
+
+
+@pytest.mark.parametrize("scale_exp", [0, 100, -100, 140, 200, -200])
+def test_fast_math_is_bit_identical_and_falls_back_outside_its_window(scale_exp):
+    """Option "fast_math" (default 1): inside the operand window [2^-150, 2^150] divisions and square roots run the
+    compiler's own sequences without range scaffolding, with reciprocals refined once per token / fee tier; the trades
+    must be THE SAME BITS as with fast_math = 0 and as the CPU restatement's (IEEE / and sqrt).  Pools scaled beyond
+    the window (2^±200) make the upload clear the segment's flag: still the same bits, through the compiler's forms."""
+    n = 96
+    batches = _wide_market(n, 501, scale_exp)
+    v = synth.sweep_prices(n, seed=77)
+    res = {}
+    for fast in (1, 0):
+        be = cr.DeviceBackend(n, batches)
+        be.ctx.set_option("fast_math", fast)
+        try:
+            psi, acc = be.find_arb(v)
+            res[fast] = (psi, acc) + be.trades()
+        finally:
+            be.close()
+    np.testing.assert_array_equal(res[1][2], res[0][2])
+    np.testing.assert_array_equal(res[1][3], res[0][3])
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    assert res[1][1] == res[0][1]
+    Do, Lo, psi_o, _ = oracle_sweep(batches, n, v, nthreads=8)
+    g0, g1 = 60_000, 90_000     # ProductTwoCoin and UniV3 rows: bit-exact against the CPU restatement
+    np.testing.assert_array_equal(res[1][2][:g0], Do[:g0])
+    np.testing.assert_array_equal(res[1][3][:g0], Lo[:g0])
+    np.testing.assert_array_equal(res[1][2][g1:], Do[g1:])
+    np.testing.assert_array_equal(res[1][3][g1:], Lo[g1:])
+
+
+@pytest.mark.parametrize("vscale", [2.0 ** 160, 2.0 ** -160, 1.0])
+def test_fast_math_price_window_is_checked_by_every_block(vscale):
+    """Prices outside the window (or a mix) are detected while the blocks stage them: the launch then takes the
+    compiler's division / square-root sequences -- same bits as fast_math = 0, also through cfmm_sweep_dev where the
+    library never sees the prices on the host."""
+    import torch
+    n = 64
+    batches = [synth.product_pools(80_000, n, seed=611), synth.univ3_pools(9_000, n, 4, seed=612)]
+    v = synth.sweep_prices(n, seed=613)
+    v[::3] *= vscale                      # a third of the tokens far outside (price ratios up to 2^±160)
+    res = {}
+    for fast in (1, 0):
+        be = cr.DeviceBackend(n, batches)
+        be.ctx.set_option("fast_math", fast)
+        try:
+            vt = torch.from_numpy(v).cuda()
+            ot = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+            be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
+            torch.cuda.synchronize()
+            res[fast] = (ot.cpu().numpy(),) + be.trades()
+        finally:
+            be.close()
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, b)
+    Do, Lo, _, _ = oracle_sweep(batches, n, v, nthreads=8)
+    np.testing.assert_array_equal(res[1][1], Do)
+    np.testing.assert_array_equal(res[1][2], Lo)

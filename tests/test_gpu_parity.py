@@ -162,14 +162,14 @@ def test_univ3_deep_walks_wave_cooperative(t):
     np.testing.assert_array_equal(L, Lo)
 
 
-@pytest.mark.parametrize("unroll", [1, 2, 4])
+@pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("copies", [1, 2])
-@pytest.mark.parametrize("block", [256, 512, 1024])
-def test_product_launch_variants(unroll, copies, block):
+@pytest.mark.parametrize("block", [512, 1024])
+def test_product_launch_variants(fast, copies, block):
     m, n = 70_001, 96
     b = synth.product_pools(m, n, seed=3)
     v = synth.sweep_prices(n, seed=4)
-    D, L, psi, acc = device_sweep([b], n, v, unroll=unroll, bin_copies=copies, max_grid=7, block=block)
+    D, L, psi, acc = device_sweep([b], n, v, fast_math=fast, bin_copies=copies, max_grid=7, block=block)
     Do, Lo, psio, acco = oracle_sweep([b], n, v)
     np.testing.assert_array_equal(D, Do)
     np.testing.assert_array_equal(L, Lo)

@@ -313,7 +313,7 @@ def test_c_abi_error_codes_without_device():
     assert L.cfmm_ctx_create(0, (1 << 26) + 1, C.byref(h)) == -4
     assert L.cfmm_pools_count(None) == 0 and L.cfmm_n_tokens(None) == 0 and L.cfmm_segment_count(None) == 0
     assert L.cfmm_set_stream(None, None) == -1 and L.cfmm_find_arb(None, None) == -1
-    assert L.cfmm_peer_allreduce(None, None, 1, 0, 4, 1, None) == -1
+    assert L.cfmm_peer_buffer_bytes(512) == 4 * 513 * 8 and L.cfmm_set_peers(None, None, 0, 0, 0) == -1
     assert b"gfx950" in L.cfmm_version()
 
 
