@@ -71,7 +71,7 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     int sweeps = 0, rc_inner = CFMM_OK;
     double sweep_s = 0.0;
     const auto t_begin = std::chrono::steady_clock::now();
-    const bool armed = can_arm(c);
+    bool armed = can_arm(c);   // (switched off for the rest of the call after a lost hand-over)
     struct ArmGuard {   // whatever path leaves this function: no launch stays behind waiting for a price vector
         cfmm_ctx* c;
         ~ArmGuard() { armed_cancel(c); }
@@ -79,7 +79,14 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     auto timed_sweep = [&](const double* x, bool mat) {
         const auto t0 = std::chrono::steady_clock::now();
         if (mat) armed_cancel(c);
-        const int rc = (armed && !mat) ? armed_eval(c, x) : host_sweep(c, x, mat);
+        int rc;
+        if (armed && !mat) {
+            bool lost = false;
+            rc = armed_eval(c, x, &lost);
+            if (lost) armed = false;
+        } else {
+            rc = host_sweep(c, x, mat);
+        }
         sweep_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ++sweeps;
         return rc;

@@ -115,15 +115,23 @@ void plan_xcd_map(cfmm_ctx* c, Group& g)
     g.xcd_map = true;
 }
 
+// Prices are staged in LDS as {v, rcp_refined(v)} pairs unless the market is too wide for them (sweep.h SweepArgs::v_shift)
+bool stage_pairs(const cfmm_ctx* c, int block)
+{
+    return !global_bins(c) && sweep_lds_bytes(c->n_pad, 1, block, 1, kMaxFeeTable, 1) <= 160 * 1024;
+}
+
 int bin_copies(const cfmm_ctx* c, int block)
 {
     if (global_bins(c)) return 1;
     const int waves = block / 64;
     if (c->opt_bin_copies == 1) return 1;
-    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block, 1, kMaxFeeTable);   // incl. the log-price row and the fee table a launch may stage
+    // incl. the log-price row and the fee table a launch may stage
+    const size_t per_wave = sweep_lds_bytes(c->n_pad, waves, block, 1, kMaxFeeTable, stage_pairs(c, block) ? 1 : 0);
     if (c->opt_bin_copies == 2) return per_wave <= 160 * 1024 ? waves : 1;
-    // auto: one private copy per wavefront while two blocks still fit a CU's 160 KiB of LDS
-    return per_wave <= (block == kBigBlock ? 80 : 48) * 1024 ? waves : 1;
+    // auto: one private copy per wavefront while the launch geometry's blocks still fit a CU's 160 KiB of LDS together
+    // (1024-thread blocks: one per CU; 512-thread blocks: two)
+    return per_wave <= (block == kBigBlock ? 128 : 64) * 1024 ? waves : 1;
 }
 
 // Large-market mode: token -> (pool, side) incidence in CSR form, cut into chunks of at most
@@ -241,7 +249,7 @@ int ensure_geometry(cfmm_ctx* c)
             bool ok = c->opt_pack != 0 && !global_bins(c);
             for (int k = 0; k < g.nseg && ok; ++k) {
                 const Segment& sg = c->segs[(size_t)g.first + k];
-                if (!sg.pk) ok = false;
+                if (!sg.pk || sg.gvals.empty()) ok = false;   // (empty: the segment has more fee tiers than a table holds)
                 total += (int)sg.gvals.size();
             }
             g.gtab_n = ok && total <= kMaxFeeTable ? total : 0;
@@ -323,12 +331,15 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.v = d_v;
         a.n = c->n;
         a.n_pad = c->n_pad;
+        a.v_shift = stage_pairs(c, g.block) ? 4 : 3;
         a.gtab = c->d_gtab ? c->d_gtab + gi * kMaxFeeTable : nullptr;
         a.gtab_n = a.gtab ? g.gtab_n : 0;
         a.need_logv = 0;
         if (!gb && c->opt_geomean_exact == 0)
             for (int k = 0; k < g.nseg; ++k)
                 if (c->segs[(size_t)g.first + k].kind == CFMM_KIND_GEOMEAN) a.need_logv = 1;
+        if (a.need_logv && sweep_lds_bytes(c->n_pad, 1, g.block, 1, a.gtab_n, a.v_shift == 4 ? 1 : 0) > 160 * 1024)
+            a.need_logv = 0;   // the log-price row does not fit next to v and one bin copy: one logarithm per pool instead
         a.copies = bin_copies(c, g.block);
         a.compact = (c->opt_compact_trades != 0 && !gb) ? 1 : 0;
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
@@ -336,7 +347,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.arm_word = arm_word;
         a.arm_seq = arm_seq;
         a.arm_timeout = std::min<long long>(std::max<long long>(c->opt_arm_timeout_ms, 1), 10000) * 100000ll;   // ms -> ticks of the 100 MHz wall clock, at most 10 s
-        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double) : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n);
+        const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double)
+                              : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n, a.v_shift == 4 ? 1 : 0);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (timed) { // start/stop written by the command processor around this launch (hipExtLaunchKernel)
             ea = take_event(c);
@@ -344,14 +356,14 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             if (!ea || !eb) ea = eb = nullptr;
         }
         auto fast_ok = [&](const Segment& s) { return (c->opt_fast_math != 0 && s.fast_ok != 0 && !gb) ? 1 : 0; };
-        auto product_of = [&](const Segment& s) { return ProductPools{s.R, s.gamma, s.Ai, a.gtab_n ? s.pk : nullptr, s.gbase}; };
-        auto geomean_of = [&](const Segment& s, bool packed) {
-            return GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, packed ? s.pk : nullptr, s.gbase};
+        const auto gbase_of = [&](const Segment& s) { return a.gtab_n ? s.gbase : -1; };   // -1: fees from the gamma array
+        auto product_of = [&](const Segment& s) { return ProductPools{s.R, s.gamma, s.Ai, s.pk, gbase_of(s)}; };
+        auto geomean_of = [&](const Segment& s) {
+            return GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, s.pk, gbase_of(s)};
         };
         auto univ3_of = [&](const Segment& s) {
             return UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ks, s.dt, s.rout,
-                              c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0), s.has_walk, s.cp,
-                              a.gtab_n ? s.pk : nullptr, s.gbase};
+                              c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0), s.has_walk, s.cp, s.pk, gbase_of(s)};
         };
         hipError_t e = hipSuccess;
         if (g.multi) {
@@ -376,7 +388,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 ms.gflow = gb ? c->d_flow + s.trade_off : nullptr;
                 switch (s.kind) {
                 case CFMM_KIND_PRODUCT: ms.pools.p = product_of(s); break;
-                case CFMM_KIND_GEOMEAN: ms.pools.g = geomean_of(s, a.gtab_n != 0); break;
+                case CFMM_KIND_GEOMEAN: ms.pools.g = geomean_of(s); break;
                 default: ms.pools.u = univ3_of(s); break;
                 }
             }
@@ -393,7 +405,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             LaunchCfg cfg{g.block, g.grid, lds, ea, eb};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(product_of(s), a, cfg, materialize, c->stream); break;
-            case CFMM_KIND_GEOMEAN: e = launch_sweep(geomean_of(s, a.gtab_n != 0 && c->opt_geomean_exact == 0), a, cfg, materialize, c->stream); break;
+            case CFMM_KIND_GEOMEAN: e = launch_sweep(geomean_of(s), a, cfg, materialize, c->stream); break;
             default: e = launch_sweep(univ3_of(s), a, cfg, materialize, c->stream); break;
             }
         }
@@ -634,6 +646,18 @@ int armed_signal(cfmm_ctx* c, const double* v, uint64_t& want, bool& signalled)
     return armed_enqueue(c);   // evaluation k+1 goes out while k runs
 }
 
+// The signalled evaluation is lost: cancel the launch queued behind it, drain the stream, and put the bookkeeping back
+// to where an unarmed run would be (the lost launch swept nothing useful: the retry takes its tile direction).  On a
+// cfmm_set_peers context a lost evaluation is fatal -- the other ranks have moved on with it.
+void armed_lost(cfmm_ctx* c, bool& retry)
+{
+    armed_cancel_single(c);
+    (void)hipStreamSynchronize(c->stream);
+    c->have_out = false;
+    retry = c->peers.empty();
+    if (retry) --c->sweep_count;
+}
+
 // Wait for the signalled evaluation's granules.  CFMM_ERR_STATE with `lost` set: the device never delivered (host
 // stalled past arm_timeout_ms between two evaluations, or the device never saw the word): the caller may retry unarmed.
 int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
@@ -650,19 +674,13 @@ int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if (!seen) {
-        armed_cancel_single(c);
-        (void)hipStreamSynchronize(c->stream);
-        c->have_out = false;
-        lost = true;
+        armed_lost(c, lost);
         return fail(c, CFMM_ERR_STATE, "armed evaluation did not complete (the device never saw its price vector)");
     }
     // a block that gave up waiting for its prices poisons the dual column with NaN: the evaluation is lost, not wrong
     const double acc = c->h_stage[2 * c->n];
     if (acc != acc) {
-        armed_cancel_single(c);
-        (void)hipStreamSynchronize(c->stream);
-        c->have_out = false;
-        lost = true;
+        armed_lost(c, lost);
         return fail(c, CFMM_ERR_STATE, "armed evaluation gave up waiting for its price vector (host stalled longer than arm_timeout_ms)");
     }
     int rc = take_host_out(c);
@@ -690,11 +708,17 @@ void armed_cancel(cfmm_ctx* c)
 
 // One fused evaluation at v through the armed launches.  A lost evaluation (see armed_wait) is retried ONCE through the
 // launch-when-ready path before the call fails: a host that was paused between two evaluations (debugger, SIGSTOP,
-// oversubscription) costs a retry, not the route.
-int armed_eval(cfmm_ctx* c, const double* v)
+// oversubscription) costs a retry, not the route.  *lost_out tells the caller (cfmm_route stops arming for the rest of
+// the call: whatever stalled the hand-over once -- e.g. another process's launches holding this GPU's CUs -- may do so again).
+int armed_eval(cfmm_ctx* c, const double* v, bool* lost_out)
 {
+    if (lost_out) *lost_out = false;
     int rc = check_prices(c, v);
     if (rc != CFMM_OK) return rc;
+    if (c->opt_debug_stall_ms > 0 && c->arm_pending) {   // test hook: the host "stalls" once while a launch waits for its prices
+        std::this_thread::sleep_for(std::chrono::milliseconds(c->opt_debug_stall_ms));
+        c->opt_debug_stall_ms = 0;
+    }
     if (!is_parent(c)) {
         uint64_t want = 0;
         bool signalled = false;
@@ -704,6 +728,7 @@ int armed_eval(cfmm_ctx* c, const double* v)
         rc = armed_wait(c, want, lost);
         if (rc != CFMM_OK && lost) {
             armed_cancel_single(c);
+            if (lost_out) *lost_out = true;
             return single_host_sweep(c, v, false);
         }
         if (rc != CFMM_OK) return rc;
@@ -736,6 +761,7 @@ int armed_eval(cfmm_ctx* c, const double* v)
     }
     if (any_lost) {
         armed_cancel(c);
+        if (lost_out) *lost_out = true;
         return multi_host_sweep(c, v, false);
     }
     if (first_err != CFMM_OK) {

@@ -23,43 +23,47 @@ bool in_fast_window(double x)
     return e >= 1023 - kFastExp && e <= 1023 + kFastExp;
 }
 
-// Packed fee + token record of a two-coin segment (sweep.h PackedFeeTok): built when the token ids fit 16 bits and the
-// segment has at most kMaxFeeTable distinct fees; otherwise the segment keeps pk == null and sweeps read gamma / Ai.
+// Packed fee + token record of a segment (sweep.h PackedFeeTok): {i1 | i2 << 16, index of the pool's fee among the
+// segment's distinct fees}.  Built for every segment outside large-market mode (token ids fit 16 bits there); a segment
+// with more than kMaxFeeTable distinct fees keeps the records for the tokens only (gvals empty: its launches read the
+// fee from the gamma array).
 int build_packed(cfmm_ctx* c, Segment& s, int64_t m, const double* gamma, const int32_t* Ai)
 {
     s.pk = nullptr;
     s.gvals.clear();
-    if (global_bins(c) || c->n > 65536 || m == 0) return CFMM_OK;
+    if (global_bins(c) || m == 0) return CFMM_OK;
     std::vector<PackedFeeTok> pk((size_t)m);
     std::vector<double> vals;
     uint64_t last_bits = 0;
     uint32_t last_idx = 0;
-    bool have_last = false;
+    bool have_last = false, table = true;
     for (int64_t i = 0; i < m; ++i) {
-        uint64_t bits;
-        std::memcpy(&bits, &gamma[i], sizeof bits);
-        uint32_t idx;
-        if (have_last && bits == last_bits) {
-            idx = last_idx;
-        } else {
-            idx = (uint32_t)vals.size();
-            for (uint32_t k = 0; k < (uint32_t)vals.size(); ++k) {   // <= 256 entries: a linear scan beats a hash map
-                uint64_t vb;
-                std::memcpy(&vb, &vals[k], sizeof vb);
-                if (vb == bits) { idx = k; break; }
+        uint32_t idx = 0;
+        if (table) {
+            uint64_t bits;
+            std::memcpy(&bits, &gamma[i], sizeof bits);
+            if (have_last && bits == last_bits) {
+                idx = last_idx;
+            } else {
+                idx = (uint32_t)vals.size();
+                for (uint32_t k = 0; k < (uint32_t)vals.size(); ++k) {   // <= 256 entries: a linear scan beats a hash map
+                    uint64_t vb;
+                    std::memcpy(&vb, &vals[k], sizeof vb);
+                    if (vb == bits) { idx = k; break; }
+                }
+                if (idx == (uint32_t)vals.size()) {
+                    if ((int)vals.size() == kMaxFeeTable) { table = false; idx = 0; }   // too many fee tiers: no table
+                    else vals.push_back(gamma[i]);
+                }
+                last_bits = bits; last_idx = idx; have_last = true;
             }
-            if (idx == (uint32_t)vals.size()) {
-                if ((int)vals.size() == kMaxFeeTable) return CFMM_OK;   // too many fee tiers: stay unpacked
-                vals.push_back(gamma[i]);
-            }
-            last_bits = bits; last_idx = idx; have_last = true;
         }
         pk[(size_t)i].tok = (uint32_t)Ai[2 * i] | ((uint32_t)Ai[2 * i + 1] << 16);
         pk[(size_t)i].gidx = idx;
     }
     int rc = upload(c, &s.pk, pk.data(), (size_t)m);
     if (rc != CFMM_OK) return rc;
-    s.gvals.swap(vals);
+    if (table) s.gvals.swap(vals);
     return CFMM_OK;
 }
 

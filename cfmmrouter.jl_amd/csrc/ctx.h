@@ -194,6 +194,7 @@ struct cfmm_ctx {
     int64_t opt_stop_in_noise = 0; // cfmm_route: 1 = end the run when a line-search trial point sits on the rounding-noise floor
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
+    int64_t opt_debug_stall_ms = 0; // test hook: the next armed evaluation is preceded by a host stall of this length (once)
     uint64_t sweep_count = 0;
 
     // kernel timing
@@ -261,7 +262,7 @@ int single_host_sweep(cfmm_ctx* c, const double* v, bool materialize);
 int host_sweep(cfmm_ctx* c, const double* v, bool materialize);   // single device or parent
 bool can_arm(cfmm_ctx* c);
 void armed_cancel(cfmm_ctx* c);
-int armed_eval(cfmm_ctx* c, const double* v);                      // single device or parent
+int armed_eval(cfmm_ctx* c, const double* v, bool* lost_out);      // single device or parent
 
 // abi_multi.cpp
 void shard_range(int64_t m, int d, int nd, int64_t& lo, int64_t& hi);

@@ -35,8 +35,10 @@ struct ProductPools {            // src/cfmms.jl:101-111
     const double2* R;            // [m] {R1, R2}
     const double* gamma;         // [m]
     const int2* Ai;              // [m] {i1, i2}, 0-based
-    const PackedFeeTok* pk;      // [m] or null: replaces gamma + Ai in the sweep (24 B per pool instead of 32)
-    int gbase;                   // this segment's first entry in the launch's fee table
+    const PackedFeeTok* pk;      // [m] {tokens, fee-table index}: replaces Ai (and gamma) in the sweep (24 B per pool instead of
+                                 //     32); null only in large-market mode (n_tokens > kMaxLdsTokens: plain arrays)
+    int gbase;                   // this segment's first entry in the launch's fee table, or -1: no table (too many fee tiers,
+                                 //     or option "pack" = 0): the fee comes from gamma[]
 };
 struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* R;
@@ -47,7 +49,7 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const double2* Q;            // [m] {Q1, Q2}: the v-independent part of the two log-space exponents, prepared at
                                  //     upload: Q1 = log γ + log η + log R2 + η·log R1,  Q2 = η·(log γ + log R1 − log η) + log R2
     int reference_order;         // 1: evaluate with pow in the reference's operation order
-    const PackedFeeTok* pk;      // [m] or null: replaces gamma + Ai in the log-space sweep (48 B per pool instead of 56)
+    const PackedFeeTok* pk;      // see ProductPools (48 B per pool instead of 56)
     int gbase;
 };
 struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
@@ -65,7 +67,7 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     int has_walk;                // 0: no pool of the segment has a tick beyond its current one (every BoundedProduct
                                  //    pool): the walk spans are not even loaded
     const double* cp;            // [m] current_price alone, read with pk instead of pg + Ai (packed records)
-    const PackedFeeTok* pk;      // [m] or null
+    const PackedFeeTok* pk;      // see ProductPools
     int gbase;
 };
 
@@ -73,6 +75,8 @@ struct SweepArgs {
     const double* v;             // [n] device
     int n;                       // n_tokens
     int n_pad;                   // n rounded up to even (LDS row pitch)
+    int v_shift;                 // 4: prices staged in LDS as {v, rcp_refined(v)} pairs (16 B per token: the fast arithmetic's
+                                 //    divisions by a price); 3: the prices alone (markets too wide for the pairs)
     int need_logv;               // 1: also stage log v per token in LDS (launches with a log-space GeometricMean segment)
     const double* gtab;          // the launch's fee table (device), staged in LDS when gtab_n > 0
     int gtab_n;
@@ -205,7 +209,7 @@ hipError_t launch_update_two_coin(double2* R, const double* gamma, const double2
 hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const double2* ovB, double2* Delta, double2* Lambda,
                                 int64_t m, hipStream_t s);
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv = 0, int gtab_n = 0);
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab_n, int stage_y);
 hipError_t prepare_kernels(size_t max_lds_bytes);
 
 } // namespace cfmm

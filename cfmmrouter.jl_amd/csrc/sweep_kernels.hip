@@ -138,29 +138,40 @@ struct ProductOps {
         double yg;    // refined reciprocal of the fee (FAST with a fee table)
     };
     ProductPools p;
+    // GBINS (n_tokens > 8192): the plain gamma / Ai arrays.  Otherwise ALWAYS the packed {tokens, fee index} record --
+    // one load, no choice between two pointers for the compiler to merge and sink to the use (round 3: with a
+    // `pk ? pk[i] : Ai[i]` in here the record's load ended up at the TOP of the next tile, its latency exposed again) --
+    // plus the fee itself from the gamma array when the launch has no fee table (p.gbase < 0: too many fee tiers).
+    template <bool GBINS>
     __device__ __forceinline__ Raw load(int64_t i) const
     {
         Raw r;
         r.R = p.R[i];
         r.yg = 0.0;
-        if (p.pk) {
-            const PackedFeeTok k = p.pk[i];
-            r.ai = make_int2((int)k.tok, (int)k.gidx);
-            r.g = 0.0;
-        } else {
+        if constexpr (GBINS) {
             r.g = p.gamma[i];
             r.ai = p.Ai[i];
+        } else {
+            const PackedFeeTok k = p.pk[i];
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
+            r.g = p.gbase < 0 ? p.gamma[i] : 0.0;
         }
         return r;
     }
-    // after stage_prices(): take the packed record apart and look the fee up in the LDS table {γ, rcp_refined(γ)}
+    // after stage_prices(): take the packed record apart; the fee from the LDS table {γ, rcp_refined(γ)}, or -- no table --
+    // its reciprocal refined here (FAST only)
+    template <bool GBINS, bool FAST>
     __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) {
-            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+        if constexpr (!GBINS) {
             const unsigned tok = (unsigned)r.ai.x;
-            r.g = gy.x;
-            r.yg = pinned(gy.y);
+            if (p.gbase >= 0) {
+                const double2 gy = gtab_lds[p.gbase + r.ai.y];
+                r.g = gy.x;
+                r.yg = pinned(gy.y);
+            } else if constexpr (FAST) {
+                r.yg = rcp_refined(r.g);
+            }
             r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
         }
     }
@@ -243,7 +254,9 @@ struct GeoMeanOps {
         double yg;    // unused (interface of process_pool)
     };
     GeoMeanPools p;
+    template <bool GBINS>
     __device__ __forceinline__ Raw load(int64_t i) const { return Raw{p.R[i], p.w[i], p.gamma[i], p.Ai[i], 0.0}; }
+    template <bool GBINS, bool FAST>
     __device__ __forceinline__ void resolve(Raw&, const double2*) const {}
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
     // Same idea as ProductOps::solve: Δ₁,Λ₂ > 0 ⇔ γ·m₁₂·η·R₂ > R₁ and Δ₂,Λ₁ > 0 ⇔ γ·m₂₁·R₁/η > R₂
@@ -305,6 +318,7 @@ struct GeoMeanLogOps {
         double yg;
     };
     GeoMeanPools p;
+    template <bool GBINS>
     __device__ __forceinline__ Raw load(int64_t i) const
     {
         Raw r;
@@ -312,23 +326,28 @@ struct GeoMeanLogOps {
         r.Q = p.Q[i];
         r.eta = p.eta[i];
         r.yg = 0.0;
-        if (p.pk) {
-            const PackedFeeTok k = p.pk[i];
-            r.ai = make_int2((int)k.tok, (int)k.gidx);
-            r.g = 0.0;
-        } else {
+        if constexpr (GBINS) {
             r.g = p.gamma[i];
             r.ai = p.Ai[i];
+        } else {
+            const PackedFeeTok k = p.pk[i];
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
+            r.g = p.gbase < 0 ? p.gamma[i] : 0.0;
         }
         return r;
     }
+    template <bool GBINS, bool FAST>
     __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) {
-            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+        if constexpr (!GBINS) {
             const unsigned tok = (unsigned)r.ai.x;
-            r.g = gy.x;
-            r.yg = pinned(gy.y);
+            if (p.gbase >= 0) {
+                const double2 gy = gtab_lds[p.gbase + r.ai.y];
+                r.g = gy.x;
+                r.yg = pinned(gy.y);
+            } else if constexpr (FAST) {
+                r.yg = rcp_refined(r.g);
+            }
             r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
         }
     }
@@ -397,6 +416,7 @@ struct UniV3Ops {
         double yg;
     };
     UniV3Pools p;
+    template <bool GBINS>
     __device__ __forceinline__ Raw load(int64_t i) const
     {
         Raw r;
@@ -406,23 +426,28 @@ struct UniV3Ops {
         r.walk = p.has_walk ? p.walk[i] : make_int4(0, 0, 0, 0);
         r.i = i;
         r.yg = 0.0;
-        if (p.pk) {   // packed record: price alone + {tokens, fee-table index}
-            const PackedFeeTok k = p.pk[i];
-            r.pg = make_double2(p.cp[i], 0.0);
-            r.ai = make_int2((int)k.tok, (int)k.gidx);
-        } else {
+        if constexpr (GBINS) {
             r.pg = p.pg[i];
             r.ai = p.Ai[i];
+        } else {   // packed record: price alone + {tokens, fee-table index} (+ the fee itself without a table)
+            const PackedFeeTok k = p.pk[i];
+            r.pg = make_double2(p.cp[i], p.gbase < 0 ? p.pg[i].y : 0.0);
+            r.ai = make_int2((int)k.tok, (int)k.gidx);
         }
         return r;
     }
+    template <bool GBINS, bool FAST>
     __device__ __forceinline__ void resolve(Raw& r, const double2* gtab_lds) const
     {
-        if (p.pk) {
-            const double2 gy = gtab_lds[p.gbase + r.ai.y];
+        if constexpr (!GBINS) {
             const unsigned tok = (unsigned)r.ai.x;
-            r.pg.y = gy.x;
-            r.yg = pinned(gy.y);
+            if (p.gbase >= 0) {
+                const double2 gy = gtab_lds[p.gbase + r.ai.y];
+                r.pg.y = gy.x;
+                r.yg = pinned(gy.y);
+            } else if constexpr (FAST) {
+                r.yg = rcp_refined(r.pg.y);
+            }
             r.ai = make_int2((int)(tok & 0xffffu), (int)(tok >> 16));
         }
     }
@@ -456,7 +481,7 @@ struct UniV3Ops {
     {
         const double cp = r.pg.x;
         g = r.pg.y;
-        yg = FAST ? (p.pk ? r.yg : rcp_refined(g)) : 0.0;
+        yg = r.yg;
         const double pr = FAST ? div_by(px.v1, px.v2, px.y2) : px.v1 / px.v2;   // :340
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
         sd = sl = 0.0;
@@ -618,11 +643,12 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y)
 // log v (launches with a log-space GeometricMean segment), the netflow bins (one copy per wavefront, or one
 // shared copy) and one slot per wavefront for the dual-scalar fold.
 struct SweepLds {
-    double2* vy;       // [n_pad] {v, rcp_refined(v)}
+    double2* vy;       // [n_pad] {v, rcp_refined(v)}  (a.v_shift == 3: [n_pad] doubles, the prices alone)
     double2* gtab;     // [gtab_n] {γ, rcp_refined(γ)}
     double* lv;        // [n_pad] log v (only when a.need_logv)
     double* bins;      // [copies][n_pad]
-    double* wsum;      // [kWaves]
+    double* wsum;      // [kWaves] dual-scalar fold
+    double* flags;     // [kWaves + 1] stage_prices: per-wavefront "prices in the fast window", then "launch is live"
     double* my_bins;   // this wavefront's copy
 };
 
@@ -634,15 +660,16 @@ __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
     if constexpr (GBINS) {
         L.vy = nullptr;
         L.gtab = nullptr;
-        L.lv = L.bins = L.my_bins = nullptr;
+        L.lv = L.bins = L.my_bins = L.flags = nullptr;
         L.wsum = lds;
         return L;
     }
     L.vy = reinterpret_cast<double2*>(lds);
-    L.gtab = L.vy + a.n_pad;
+    L.gtab = reinterpret_cast<double2*>(lds + ((size_t)a.n_pad << (a.v_shift - 3)));
     L.lv = reinterpret_cast<double*>(L.gtab + a.gtab_n);
     L.bins = L.lv + (a.need_logv ? a.n_pad : 0);
     L.wsum = L.bins + (size_t)a.copies * a.n_pad;
+    L.flags = L.wsum + BLOCK / 64;
     L.my_bins = L.bins + (size_t)(a.copies == 1 ? 0 : (threadIdx.x >> 6)) * a.n_pad;
     return L;
 }
@@ -683,15 +710,16 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
             const double g = a.gtab[j];
             L.gtab[j] = make_double2(g, rcp_refined(g));
         }
-        if (tid == 0) L.wsum[0] = wait_armed(a) ? 1.0 : 0.0;
+        if (tid == 0) L.flags[BLOCK / 64] = wait_armed(a) ? 1.0 : 0.0;
         __syncthreads();
-        live = L.wsum[0] != 0.0;
+        live = L.flags[BLOCK / 64] != 0.0;
     }
     bool in_window = true;
     for (int j = tid; j < a.n; j += BLOCK) {
         // armed: the host wrote v through the PCIe BAR after this kernel may have started -- system-scope loads
         const double vj = armed ? __hip_atomic_load(a.v + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.v[j];
-        L.vy[j] = make_double2(vj, rcp_refined(vj));
+        if (a.v_shift == 4) L.vy[j] = make_double2(vj, rcp_refined(vj));
+        else reinterpret_cast<double*>(L.vy)[j] = vj;
         in_window = in_window && in_fast_window(vj);
         if (logs) L.lv[j] = log(vj);     // once per token per block: the only logarithm of a GeometricMean sweep
     }
@@ -703,7 +731,14 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
             L.gtab[j] = make_double2(g, rcp_refined(g));
         }
     }
-    const int all_in = __syncthreads_and(in_window ? 1 : 0);
+    // block-wide AND of in_window through LDS (the library's __syncthreads_and would add 256 bytes of STATIC LDS to
+    // every kernel, which the 160 KiB dynamic ceiling of hipFuncSetAttribute then no longer leaves room for)
+    const bool wave_in = __all(in_window ? 1 : 0) != 0;
+    if ((tid & 63) == 0) L.flags[tid >> 6] = wave_in ? 1.0 : 0.0;
+    __syncthreads();
+    bool all_in = true;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) all_in = all_in && L.flags[w] != 0.0;
     return (live ? kStageLive : 0) | (all_in ? kStageFast : 0);
 }
 
@@ -713,7 +748,7 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
                                              const typename Ops::Raw& raw_in, int64_t i, bool valid, double& acc)
 {
     typename Ops::Raw raw = raw_in;
-    if constexpr (!GBINS) ops.resolve(raw, L.gtab);   // packed records: {tokens, fee-table index} -> tokens, fee
+    ops.template resolve<GBINS, FAST>(raw, L.gtab);   // packed records: {tokens, fee-table index} -> tokens, fee
     int2 tok = make_int2(0, 0);
     if (valid) tok = ops.tokens(raw);
     Px px;                                            // v[r.cfmms[i].Ai]
@@ -724,11 +759,19 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
         px.y1 = px.y2 = 0.0;
         px.dlv = Ops::kNeedsLogPrices ? log(px.v2 / px.v1) : 0.0;   // large markets: v is not staged, one logarithm per pool
     } else {
-        const double2 a1 = L.vy[tok.x], a2 = L.vy[tok.y];
-        px.v1 = a1.x; px.y1 = a1.y;
-        px.v2 = a2.x; px.y2 = a2.y;
+        if constexpr (FAST) {   // {v, rcp_refined(v)} pairs (FAST implies a.stage_y)
+            const double2 a1 = L.vy[tok.x], a2 = L.vy[tok.y];
+            px.v1 = a1.x; px.y1 = a1.y;
+            px.v2 = a2.x; px.y2 = a2.y;
+        } else {                // pairs, or -- markets too wide for them -- the prices alone (a.v_shift = 4 / 3)
+            const char* base = reinterpret_cast<const char*>(L.vy);
+            px.v1 = *reinterpret_cast<const double*>(base + ((size_t)tok.x << a.v_shift));
+            px.v2 = *reinterpret_cast<const double*>(base + ((size_t)tok.y << a.v_shift));
+            px.y1 = px.y2 = 0.0;
+        }
         px.dlv = 0.0;
-        if constexpr (Ops::kNeedsLogPrices) px.dlv = L.lv[tok.y] - L.lv[tok.x];
+        if constexpr (Ops::kNeedsLogPrices)   // log v staged per token, or -- markets too wide for that row -- one logarithm per pool
+            px.dlv = a.need_logv ? L.lv[tok.y] - L.lv[tok.x] : log(px.v2 / px.v1);
     }
     Trade t;
     if constexpr (Ops::kWaveCooperative) ops.template solve_wave<FAST>(raw, valid, px, t);
@@ -798,7 +841,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
             if (ok) {
                 i += step;
                 ok = --left > 0;
-                if (ok) cur = ops.load(i);
+                if (ok) cur = ops.template load<GBINS>(i);
             }
         }
     } else if constexpr (CFMM_PREFETCH != 0) {
@@ -806,7 +849,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
             const bool more = left > 1;
             // unconditional request (a conditional one makes the compiler wait for it at the join, before the
             // arithmetic): the last tile re-requests itself, a cache hit
-            const typename Ops::Raw nxt = ops.load(more ? i + step : i);
+            const typename Ops::Raw nxt = ops.template load<GBINS>(more ? i + step : i);
             process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
             cur = nxt;
             i += step;
@@ -818,7 +861,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
             process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
             i += step;
             ok = --left > 0;
-            if (ok) cur = ops.load(i);
+            if (ok) cur = ops.template load<GBINS>(i);
         }
     }
 }
@@ -834,14 +877,14 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     const int64_t step = a.reverse ? -stride : stride;
     const int64_t i = a.reverse ? i0 + (left - 1) * stride : i0;
     typename Ops::Raw cur = {};
-    if (left > 0) cur = ops.load(i);
+    if (left > 0) cur = ops.template load<GBINS>(i);
     const int staged = stage_prices<BLOCK, GBINS>(a, L);
     live_out = (staged & kStageLive) != 0;
     if (!live_out) {                                  // a pre-armed launch that is not needed (or gave up)
         left = 0;
         acc = __builtin_nan("");                      // poisons the dual column should anyone fold this row
     }
-    const bool fast = !GBINS && a.fast_ok != 0 && (staged & kStageFast) != 0;   // block-uniform
+    const bool fast = !GBINS && a.fast_ok != 0 && a.v_shift == 4 && (staged & kStageFast) != 0;   // block-uniform
     if (fast) tile_loop<Ops, MAT, BLOCK, GBINS, !GBINS>(ops, a, L, cur, i, step, left, acc);
     else tile_loop<Ops, MAT, BLOCK, GBINS, false>(ops, a, L, cur, i, step, left, acc);
     return acc;
@@ -1153,9 +1196,9 @@ static void launch_k(K kernel, dim3 g, dim3 b, size_t lds, hipStream_t s, hipEve
     else hipLaunchKernelGGL(kernel, g, b, lds, s, args...);
 }
 
-size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab_n)
+size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab_n, int stage_y)
 {
-    const size_t words = (size_t)n_pad * (2 + (need_logv ? 1 : 0) + copies) + 2 * (size_t)gtab_n + block / 64;
+    const size_t words = (size_t)n_pad * ((stage_y ? 2 : 1) + (need_logv ? 1 : 0) + copies) + 2 * (size_t)gtab_n + 2 * (size_t)(block / 64) + 2;
     return words * sizeof(double);
 }
 

@@ -39,6 +39,14 @@ def uniform(seed: int, stream: int, count: int, first: int = 0):
     return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
 
 
+def uniform_at(seed: int, stream: int, counters):
+    """doubles in [0,1) at explicit counter values (same function of (seed, stream, counter) as `uniform`)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(stream))
+        bits = _splitmix64(base + np.asarray(counters, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95))
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
 def token_pairs(seed, stream, m, n_tokens, first=0):
     """Two distinct 1-based token ids per pool, uniform over ordered pairs."""
     a = np.minimum((uniform(seed, stream, m, first) * n_tokens).astype(np.int64), n_tokens - 1)
@@ -112,6 +120,57 @@ def univ3_pools(m, n_tokens, ticks_per_pool, seed=1234, first=0):
     tick_off = t * np.arange(m + 1, dtype=np.int64)
     return PoolBatch(KIND_UNIV3, current_price=p, tick_off=tick_off, lower_ticks=lower_ticks.reshape(-1),
                      liquidity=liq.reshape(-1), γ=γ, Ai=token_pairs(seed, 46, m, n_tokens, first))
+
+
+def univ3_ragged_pools(m, n_tokens, min_ticks=2, max_ticks=64, seed=1234, first=0, noise=0.01):
+    """m UniV3 pools with RAGGED tick ladders (the multi-tick workload of bench.py --workload univ3_ticks).
+
+    The reference gives no distribution (only the hand fixture test/cfmms.jl:117-119); this generator's choice, made to
+    look like a concentrated-liquidity venue: the number of initialised ticks per pool is skewed towards few
+    (t = min + floor((max − min + 1)·u³): half of the pools have <= 9 ticks at 2..64), ticks are geometric with a
+    per-pool spacing of 1 %..6 %, one tick in ten is empty, liquidity ~ 1e6·U[0.01, 1.01) per tick, and the current price
+    is the quote p = π[i₁]/π[i₂]·exp(noise·U[-1,1)) of one token price vector π (`token_price_vector`) placed anywhere
+    inside the ladder -- so at prices a few per cent off π most pools trade inside their current tick and a sizeable
+    minority walks through several.  Every value is a pure function of (seed, pool index, tick index): shards of a
+    market regenerate the same pools."""
+    Ai = token_pairs(seed, 76, m, n_tokens, first)
+    π = token_price_vector(n_tokens, seed)
+    p = π[Ai[:, 0] - 1] / π[Ai[:, 1] - 1] * np.exp(noise * (2.0 * uniform(seed, 70, m, first) - 1.0))
+    span = max_ticks - min_ticks + 1
+    t = np.minimum(min_ticks + np.floor(span * uniform(seed, 71, m, first) ** 3).astype(np.int64), max_ticks)
+    step = 1.0 + 0.01 + 0.05 * uniform(seed, 72, m, first)
+    pos = 0.5 + (t - 1) * uniform(seed, 73, m, first)          # where the current price sits in the ladder
+    tick_off = np.concatenate([[0], np.cumsum(t)]).astype(np.int64)
+    pool = np.repeat(np.arange(m, dtype=np.int64), t)
+    j = np.arange(tick_off[-1], dtype=np.int64) - tick_off[pool]
+    ctr = (np.uint64(first) + pool.astype(np.uint64)) * np.uint64(max_ticks) + j.astype(np.uint64)
+    lower_ticks = p[pool] * step[pool] ** (pos[pool] - j)
+    liq = 1e6 * (0.01 + uniform_at(seed, 74, ctr))
+    liq = np.where(uniform_at(seed, 75, ctr) < 0.1, 0.0, liq)
+    γ = np.where(uniform(seed, 77, m, first) < 0.5, 0.997, 1.0)
+    return PoolBatch(KIND_UNIV3, current_price=p, tick_off=tick_off, lower_ticks=lower_ticks, liquidity=liq, γ=γ, Ai=Ai)
+
+
+def univ3_ticks_visited(b, v):
+    """Per pool of a UniV3 batch: how many ticks find_arb! (src/cfmms.jl:339-395) looks at for prices v -- 0 inside the
+    no-arbitrage band (:347-349), else the ticks from the current one to the one that holds the target price p/γ
+    (falling) or γ·p (rising), inclusive.  (Bench bookkeeping: the algorithmic bytes of a sweep are 32 B per pool + 16 B
+    per tick VISITED)"""
+    m = len(b)
+    lt, off = b.lower_ticks, b.tick_off
+    nt = np.diff(off)
+    pool = np.repeat(np.arange(m, dtype=np.int64), nt)
+
+    def index_of(x):   # searchsortedlast(lower_ticks, x, rev = true), 1-based, per pool (:235)
+        return np.add.reduceat((lt >= x[pool]).astype(np.int64), off[:-1])
+
+    pr = v[b.Ai[:, 0] - 1] / v[b.Ai[:, 1] - 1]
+    g, cp = b.γ, b.current_price
+    ct = index_of(cp)
+    idle = (g * cp <= pr) & (pr <= cp / g)
+    target = np.where(pr < g * cp, pr / g, g * pr)
+    it = np.clip(index_of(target), 1, nt)
+    return np.where(idle, 0, np.abs(it - ct) + 1)
 
 
 def linear_prices(n_tokens, seed=1234):

@@ -24,6 +24,12 @@ market = [synth.product_pools(300_000, n, seed=81), synth.geomean_pools(100_000,
           synth.bounded_product_pools(60_000, n, seed=83, consistent=True)]
 obj = cr.LinearNonnegative(synth.linear_prices(n, seed=81))
 r = crd.ShardedRouter(obj, market, n, device=0)
+if isinstance(r._backend, cr.DeviceBackend):
+    # Several ranks on ONE GPU: a pre-armed launch polls for its prices while it occupies its CUs; with the ranks' shards of
+    # the SAME evaluation queued on the same device, one rank's waiting launch would starve the evaluation it waits for.
+    # (One rank per GPU -- the deployment -- has no such coupling; the library switches arming off by itself only for
+    # multi-device contexts that list a device twice.)
+    r._backend.ctx.set_option("armed", 0)
 out = {"world": world, "in_library_collective": isinstance(r._backend, cr.DeviceBackend),
        "buffers": type(getattr(r._backend, "peer", None)).__name__}
 v = synth.sweep_prices(n, seed=84)

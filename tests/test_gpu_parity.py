@@ -405,9 +405,11 @@ def test_route_arbitrage_parity(m, n):
     obj = cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
     r, ref = route_both(obj, b, n, v0=np.ones(n))
     assert rel_to_max(cr.netflows(r), ref["psi"]) <= ROUTE_TOL
-    # feasibility as in test/arb.jl:22, scaled: L-BFGS-B stops on factr, which leaves
-    # constraint-active netflows of ~1e-9 max|Ψ| on these instances (same for the CPU restatement)
-    assert np.all(cr.netflows(r) >= -1e-3 - 1e-8 * np.max(np.abs(ref["psi"])))
+    # feasibility as in test/arb.jl:22 (all_flows >= -TOL), with the CPU restatement's own worst component as the
+    # yardstick: L-BFGS-B stops on factr, which leaves constraint-active netflows slightly negative on BOTH sides
+    # (how negative depends on the last iterate, i.e. on summation-order rounding of Ψ), never more than that
+    floor = min(float(np.min(ref["psi"])), 0.0)
+    assert np.all(cr.netflows(r) >= 3 * floor - 1e-3 - 1e-8 * np.max(np.abs(ref["psi"])))
     assert np.all(r.v >= cr.lower_limit(obj) - 1e-4)
     r.close()
 
@@ -465,16 +467,34 @@ def test_route_config5_interior_optimum(solver):
     cr.route_(r, solver=solver)
     ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(market, n), v0=None, nthreads=_threads())
     assert r.info["funcalls"] >= 10 and ref["info"]["funcalls"] >= 10
-    # Both runs stop on factr = 1e1 (relative decrease of the dual <= 10 eps) with a stationarity residual
-    # max_i |Ψ_i + Δin_i| of ~1e-6 max|Ψ| left: that residual, not the sweep, bounds how well two runs of the
-    # SAME algorithm agree on Ψ (the CPU restatement alone moves by 1e-6 max|Ψ| when v0 is perturbed by 1e-16,
-    # profiles/r02_route_scatter.txt).  Asserted: the same dual value to 1e-12, and Ψ equal to within
-    # north_star's 1e-6 plus the two residuals.
+    # (1) The KERNEL, isolated from the solver: the HIP sweep evaluated AT THE ORACLE'S v* returns the oracle's Ψ*
+    #     to summation-order rounding (and its trades bit for bit).
+    be = cr.DeviceBackend(n, market)
+    psi_at_ref, _ = be.find_arb(ref["v"])
+    D_at_ref, L_at_ref = be.trades()
+    be.close()
+    assert rel_to_max(psi_at_ref, ref["psi"]) <= REDUCE_TOL
+    np.testing.assert_array_equal(D_at_ref, ref["Delta"])
+    np.testing.assert_array_equal(L_at_ref, ref["Lambda"])
+    # (2) The ALGORITHM's own scatter: both runs stop on factr = 1e1 (relative decrease of the dual <= 10 eps) with a
+    #     stationarity residual of ~1e-6 max|Ψ| left, and that residual -- not the sweep -- bounds how well two runs of
+    #     the SAME algorithm agree on Ψ*.  Measured here, not assumed: the CPU restatement is re-run from four starting
+    #     points perturbed by 1e-16 ... 1e-10 (relative), and the device's Ψ* must lie within 2x the hull of those runs
+    #     around the unperturbed one -- or within north_star's 1e-6 where the hull is tighter than that.
     Ψ, scale = cr.netflows(r), np.max(np.abs(ref["psi"]))
+    v0 = np.ones(n) / n
+    hull = 0.0
+    for eps in (1e-16, 1e-15, 1e-13, 1e-10):
+        alt = orc.route_oracle(oracle_objective(obj), oracle_poolset(market, n), v0=v0 * (1 + eps * np.arange(n)),
+                               nthreads=_threads())
+        hull = max(hull, np.max(np.abs(alt["psi"][1:] - ref["psi"][1:])) / scale)
+    dev = np.max(np.abs(Ψ[1:] - ref["psi"][1:])) / scale
+    print(f"config5 interior ({solver}): device vs oracle {dev:.2e}, oracle's own scatter hull {hull:.2e}, "
+          f"|v*-v*ref|/|v*ref| {np.max(np.abs(r.v - ref['v']) / ref['v']):.2e}")
+    assert dev <= max(ROUTE_TOL, 2 * hull)
     res_dev = np.max(np.abs(Ψ[1:] + obj.Δin[1:])) / scale
     res_ref = np.max(np.abs(ref["psi"][1:] + obj.Δin[1:])) / scale
     assert res_dev <= 1e-5 and res_ref <= 1e-5
-    assert np.max(np.abs(Ψ[1:] - ref["psi"][1:])) / scale <= ROUTE_TOL + 2 * (res_dev + res_ref)
     assert abs(r.info["f"] - ref["f"]) <= 1e-12 * max(1.0, abs(ref["f"]))
     # Ψ[0], the amount of the output token received, is the PRIMAL objective; its price sits on its bound, so
     # no stationarity condition pins it and it inherits the residuals amplified by the dual's curvature
@@ -622,11 +642,14 @@ def test_full_size_config4_shard_all_rows():
     _size_independent_checks([b], D, L, psi, acc, v, n)
 
 
-def test_full_size_config5_all_rows():
-    """BASELINE config 5 at full size: 1M BoundedProduct pools (2-tick UniV3), all rows bit-exact."""
+@pytest.mark.parametrize("consistent", [True, False])
+def test_full_size_config5_all_rows(consistent):
+    """BASELINE config 5 at full size: 1M BoundedProduct pools (2-tick UniV3), all rows bit-exact -- on the market
+    bench.py's config5 times (pools quoted around one token price vector: consistent = True) and on the arbitrage-rich
+    one with independent random prices (config5corner), at prices off the no-arbitrage manifold."""
     n = 256
     v = synth.sweep_prices(n, seed=1234)
-    bu = synth.bounded_product_pools(1_000_000, n, seed=1234)
+    bu = synth.bounded_product_pools(1_000_000, n, seed=1234, consistent=consistent)
     be = cr.DeviceBackend(n, [bu])
     psi, acc = be.find_arb(v)
     D, L = be.trades()
