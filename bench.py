@@ -663,15 +663,22 @@ def main():
             for _ in range(50):
                 fn()
             host[name + "_us"] = 1e6 * (time.perf_counter() - t0) / 50
+        # r.Δs / r.Λs on the host (src/router.jl:7-8): into arrays the caller owns (what the Julia binding fills) and into
+        # freshly allocated ones (numpy.empty: the copy then also pays one page fault per 4 KiB of destination)
         be.find_arb(v)
-        be.trades()                                  # (the first call allocates the pinned staging)
-        ts = []
+        own = be.trades()                            # (the first call allocates the pinned staging)
+        ts, tf = [], []
         for _ in range(3):
             be.find_arb(v)
             t0 = time.perf_counter()
-            be.trades()
+            be.trades(out=own)
             ts.append(time.perf_counter() - t0)
+            be.find_arb(v)
+            t0 = time.perf_counter()
+            be.trades()
+            tf.append(time.perf_counter() - t0)
         host["get_trades_ms"] = 1e3 * min(ts)
+        host["get_trades_fresh_arrays_ms"] = 1e3 * min(tf)
         host["pools_per_s_host_call_find_arb"] = sb.m_rank / (host["find_arb_us"] * 1e-6)
         be.ctx.set_stream(sb.stream.cuda_stream)
 

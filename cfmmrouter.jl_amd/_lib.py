@@ -271,9 +271,17 @@ class Context:
         self._check(self._L.cfmm_eval(self._h, ptr(v), ptr(psi), C.byref(acc)))
         return psi, acc.value
 
-    def trades(self):
+    def trades(self, out=None):
+        """r.Δs / r.Λs of the latest materialising sweep as [m, 2] arrays (cfmm_get_trades).  `out` = (Δ, Λ): fill
+        caller-owned C-contiguous float64 arrays instead of allocating (what a binding that owns r.Δs / r.Λs does)."""
         m = self.pool_count
-        D, Lm = np.empty((m, 2)), np.empty((m, 2))
+        if out is None:
+            D, Lm = np.empty((m, 2)), np.empty((m, 2))
+        else:
+            D, Lm = out
+            for a in (D, Lm):
+                if a.dtype != np.float64 or a.shape != (m, 2) or not a.flags.c_contiguous:
+                    raise ArgumentError("out arrays must be C-contiguous float64 of shape [m, 2]")
         self._check(self._L.cfmm_get_trades(self._h, ptr(D), ptr(Lm)))
         return D, Lm
 

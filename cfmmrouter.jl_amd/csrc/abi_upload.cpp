@@ -110,7 +110,7 @@ void free_segment(Segment& s)
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
     (void)hipFree(s.eta); (void)hipFree(s.lR); (void)hipFree(s.pk);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
-    (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ks); (void)hipFree(s.dt); (void)hipFree(s.rout);
+    (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ticks);
     s = Segment{};
 }
 
@@ -120,14 +120,13 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
 {
     const int64_t T = m > 0 ? tick_off[m] : 0;
     if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
-    std::vector<double2> pg((size_t)m), ks, dt, cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
-    std::vector<double> rout, cur_c((size_t)m);
+    std::vector<double2> pg((size_t)m), cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
+    std::vector<double> cur_c((size_t)m);
+    std::vector<TickRec> ticks;
     std::vector<int4> walk((size_t)m);
     int longest = 0;
     bool fast = true;   // every operand of the sweep's divisions / square roots inside the fast window (sweep.h)
-    ks.reserve((size_t)T + (size_t)m);
-    dt.reserve((size_t)T + (size_t)m);
-    rout.reserve((size_t)T + (size_t)m);
+    ticks.reserve((size_t)T);
     for (int64_t i = 0; i < m; ++i) {
         const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
         if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
@@ -184,29 +183,25 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
             if (k == 0) { cur_b[(size_t)i].y = 0.0; cur_c[(size_t)i] = 0.0; } // 0/0: never read (k == 0 is skipped)
         }
         int4 w;
-        w.x = (int)ks.size();
+        w.x = (int)ticks.size();
         int cnt = 0;
         for (int64_t idx = ct + 1; idx <= nt; ++idx) {        // get_upper_pools beyond the current tick, :316
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;                             // is_empty_pool, :288
             const double s_in = R1 + al;
-            ks.push_back(make_double2(k, s_in));
-            dt.push_back(make_double2(k / be - s_in, R2 + be)); // :329, :334
-            rout.push_back(R2);
+            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(k / be - s_in, R2 + be), R2, {0.0, 0.0, 0.0}});   // :329, :334
             ++cnt;
         }
         w.y = cnt;
-        w.z = (int)ks.size();
+        w.z = (int)ticks.size();
         cnt = 0;
         for (int64_t idx = ct - 1; idx >= 1; --idx) {         // flip_sides.(get_lower_pools), :317,:289
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;
             const double s_in = R2 + be;
-            ks.push_back(make_double2(k, s_in));
-            dt.push_back(make_double2(k / al - s_in, R1 + al));
-            rout.push_back(R1);
+            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(k / al - s_in, R1 + al), R1, {0.0, 0.0, 0.0}});
             ++cnt;
         }
         w.w = cnt;
@@ -225,8 +220,7 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
         (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
         (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
-        (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ks, ks.data(), ks.size())) ||
-        (rc = upload(c, &s.dt, dt.data(), dt.size())) || (rc = upload(c, &s.rout, rout.data(), rout.size())) ||
+        (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ticks, ticks.data(), ticks.size())) ||
         (rc = upload(c, &s.cp, current_price, (size_t)m)) || (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;

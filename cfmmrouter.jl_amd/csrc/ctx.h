@@ -51,9 +51,7 @@ struct Segment {
     double* cur_c = nullptr;
     double2* curR = nullptr;
     int4* walk = nullptr;
-    double2* ks = nullptr;
-    double2* dt = nullptr;
-    double* rout = nullptr;
+    TickRec* ticks = nullptr;   // univ3: walk lists (sweep.h TickRec)
     // launch geometry (decided by ensure_geometry)
     int block = kMidBlock;
     int grid = 0;

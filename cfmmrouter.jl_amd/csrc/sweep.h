@@ -52,6 +52,15 @@ struct GeoMeanPools {            // src/cfmms.jl:152-165
     const PackedFeeTok* pk;      // see ProductPools (48 B per pool instead of 56)
     int gbase;
 };
+// One tick of a walk list (UniV3Ops::list_tick): everything find_arb_pos (src/cfmms.jl:321-337) needs for one prepared
+// tick in ONE 64-byte line -- lanes walk different pools, so every tick visit is a scattered access; round 2 kept
+// {k, s_in}, {δmax, s_out} and R_out in three arrays = three lines per visit.
+struct alignas(64) TickRec {
+    double2 ks;                  // {k, R_in + alpha_in}
+    double2 dt;                  // {delta_max, R_out + beta_out}
+    double rout;                 // R_out
+    double pad[3];
+};
 struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
     const double2* pg;           // [m] {current_price, gamma}
     const int2* Ai;              // [m]
@@ -60,9 +69,7 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     const double* cur_c;         // [m] current tick  k/alpha - (R2+beta)
     const double2* curR;         // [m] current tick {R1, R2}
     const int4* walk;            // [m] ticks beyond the current one: {up_begin, up_count, lo_begin, lo_count}
-    const double2* ks;           // [W] {k, R_in + alpha_in}
-    const double2* dt;           // [W] {delta_max, R_out + beta_out}
-    const double* rout;          // [W] R_out
+    const TickRec* ticks;        // [W] the walk lists: per pool the non-empty ticks above, then below, its current one
     int deep;                    // 1: some walk list is long -> wavefront-cooperative kernel (UniV3CoopOps)
     int has_walk;                // 0: no pool of the segment has a tick beyond its current one (every BoundedProduct
                                  //    pool): the walk spans are not even loaded

@@ -120,6 +120,20 @@ struct Px {
     double v1, v2, y1, y2, yg, dlv;
 };
 
+// What Ops::solve_dir returns: a two-coin pool trades in at most one direction (the reference's four outputs are
+// (Δ₁, 0), (0, Λ₂) or (0, Δ₂), (Λ₁, 0)), so the common case travels as {d, l} + a direction and the epilogue of a pool
+// (trade record, dual scalar, netflow bins) works on two values instead of four.  kDirBoth: all four values in a Trade
+// (γ > 1 pools trading both ways, the overlap of ProductTwoCoin's predicates, NaN prices).
+constexpr int kDirNone = 0, kDir1 = 1, kDir2 = 2, kDirBoth = 3;
+__device__ __forceinline__ void expand_dir(int dir, double d, double l, Trade& t)
+{
+    if (dir == kDirBoth) return;
+    t.d1 = dir == kDir1 ? d : 0.0;
+    t.d2 = dir == kDir2 ? d : 0.0;
+    t.l1 = dir == kDir2 ? l : 0.0;
+    t.l2 = dir == kDir1 ? l : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ProductTwoCoin -- src/cfmms.jl:125-140
 // ---------------------------------------------------------------------------------------------
@@ -195,19 +209,20 @@ struct ProductOps {
     // the selected operands, hence bit-identical values.  The predicates carry a 1e-12 relative
     // margin (>> the 1e-16 rounding of the forms), so a direction is only skipped where the
     // reference's max(·, 0) provably clamps to 0; the (measure-zero) overlap runs the full forms.
+    // Returns the direction of the trade: kDirNone, kDir1 (Δ₁ = d, Λ₂ = l), kDir2 (Δ₂ = d, Λ₁ = l) or kDirBoth
+    // (the four values in t: the overlap of the two predicates, or NaN inputs).
     template <bool FAST>
-    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
+    __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
     {
         const double R1 = r.R.x, R2 = r.R.y, g = r.g, v1 = px.v1, v2 = px.v2;
         constexpr double kMargin = 1.0 + 1e-12;
         const double a = v1 * R1, b = v2 * R2;
         const bool p1 = (g * b) * kMargin >= a;    // direction 1 possibly active
         const bool p2 = (g * a) * kMargin >= b;    // direction 2 possibly active
-        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        d = l = 0.0;
         if (p1 != p2) {
             const double k = R1 * R2;                          // :132
             const double r_in = p1 ? R1 : R2, r_out = p1 ? R2 : R1;
-            double d, l;
             if constexpr (FAST) {
                 // m = v_out / v_in through the divisor's staged reciprocal; operands inside the window: same bits
                 const double gm = g * div_by(p1 ? v2 : v1, p1 ? v1 : v2, p1 ? px.y1 : px.y2);
@@ -218,15 +233,15 @@ struct ProductOps {
                 d = max0(sqrt(gm * k) - r_in) / g;             // :125
                 l = max0(r_out - sqrt(k / gm));                // :126
             }
-            t.d1 = p1 ? d : 0.0;
-            t.d2 = p1 ? 0.0 : d;
-            t.l1 = p1 ? 0.0 : l;
-            t.l2 = p1 ? l : 0.0;
-        } else if (p1 || a != a || b != b) {
+            return p1 ? kDir1 : kDir2;
+        }
+        if (p1 || a != a || b != b) {
             // both directions within the margin (γ ≈ 1 at the no-arbitrage price), or a NaN among the inputs
             // (both predicates are false on NaN): the reference's four forms, which propagate it
             solve_full(R1, R2, g, v1, v2, t);
+            return kDirBoth;
         }
+        return kDirNone;
     }
 };
 
@@ -263,6 +278,12 @@ struct GeoMeanOps {
     // (the bases of :180 exceed r2^(η+1)); only the live direction's two forms (4 pow instead of
     // 8) are evaluated, with the reference's expressions on the selected operands.
     template <bool FAST>   // (no fast variant: pow dominates and the forms keep the reference's operation order)
+    __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
+    {
+        d = l = 0.0;
+        solve(r, px, t);
+        return kDirBoth;
+    }
     __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
     {
         const double v1 = px.v1, v2 = px.v2;
@@ -352,40 +373,45 @@ struct GeoMeanLogOps {
         }
     }
     __device__ __forceinline__ int2 tokens(const Raw& r) const { return r.ai; }
+    // one direction of the log-space forms: {d, l} for direction 1 (dir1) or 2
     template <bool FAST>
-    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
+    __device__ __forceinline__ void one_direction(const Raw& r, const Px& px, bool dir1, double n, double dd, double& d, double& l) const
     {
-        const double v1 = px.v1, v2 = px.v2, dlv = px.dlv;   // dlv = log v2 − log v1
+        const double R1 = r.R.x, R2 = r.R.y, g = r.g, eta = r.eta;
+        const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
+        const double A = dir1 ? (r.Q.x + px.dlv) : (r.Q.y - eta * px.dlv);
+        double X, Y;
+        if constexpr (FAST) {   // same correctly rounded quotients for operands inside the window (checked at upload / staging)
+            X = exp(fast_div(A, eta + 1.0));
+            Y = fast_div((X * ra) * dd, n);
+            d = div_by(max0(X - rb), g, px.yg);
+        } else {
+            X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
+            Y = ((X * ra) * dd) / n;      // X·r_a/c, c = n/d
+            d = max0(X - rb) / g;
+        }
+        l = max0(ra - Y);
+    }
+    template <bool FAST>
+    __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
+    {
+        const double v1 = px.v1, v2 = px.v2;                 // px.dlv = log v2 − log v1
         const double R1 = r.R.x, R2 = r.R.y, g = r.g;
         const double eta = r.eta;                     // η = w₁/w₂, prepared at upload
         const double n1 = ((g * v2) * eta) * R2, d1 = v1;   // c₁ = n1/d1: direction 1 trades iff c₁ > R₁
         const double n2 = (g * v1) * R1, d2 = v2 * eta;     // c₂ = n2/d2: direction 2 trades iff c₂ > R₂
         const bool p1 = n1 > R1 * d1, p2 = n2 > R2 * d2;
-        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        if (v1 != v1 || v2 != v2) { t.d1 = t.d2 = t.l1 = t.l2 = v1 + v2; return; }   // NaN prices propagate (reference: pow of NaN)
-        // pass 0: the (normally only) live direction.  pass 1: direction 2 when BOTH are live, which
-        // needs γ > 1 -- kept as a second trip through the same code (not a second copy of it) so the
-        // kernel's register footprint is that of one direction.
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            const bool dir1 = pass == 0 && p1;
-            if (pass == 0 ? !(p1 || p2) : !(p1 && p2)) break;
-            const double ra = dir1 ? R2 : R1, rb = dir1 ? R1 : R2;
-            const double A = dir1 ? (r.Q.x + dlv) : (r.Q.y - eta * dlv);
-            double X, Y, d;
-            if constexpr (FAST) {   // same correctly rounded quotients for operands inside the window (checked at upload / staging)
-                X = exp(fast_div(A, eta + 1.0));
-                Y = fast_div((X * ra) * (dir1 ? d1 : d2), dir1 ? n1 : n2);
-                d = div_by(max0(X - rb), g, px.yg);
-            } else {
-                X = exp(A / (eta + 1.0));     // the tendered side's reserve after the trade
-                Y = ((X * ra) * (dir1 ? d1 : d2)) / (dir1 ? n1 : n2);   // X·r_a/c, c = n/d
-                d = max0(X - rb) / g;
-            }
-            const double l = max0(ra - Y);
-            if (dir1) { t.d1 = d; t.l2 = l; }
-            else { t.d2 = d; t.l1 = l; }
-        }
+        d = l = 0.0;
+        if (v1 != v1 || v2 != v2) { t.d1 = t.d2 = t.l1 = t.l2 = v1 + v2; return kDirBoth; }   // NaN prices propagate (reference: pow of NaN)
+        if (!(p1 || p2)) return kDirNone;
+        // the (normally only) live direction
+        one_direction<FAST>(r, px, p1, p1 ? n1 : n2, p1 ? d1 : d2, d, l);
+        if (!(p1 && p2)) return p1 ? kDir1 : kDir2;
+        // BOTH directions live (needs γ > 1): direction 2 as a second trip through the same code
+        t.d1 = d;
+        t.l2 = l;
+        one_direction<FAST>(r, px, false, n2, d2, t.d2, t.l1);
+        return kDirBoth;
     }
 };
 
@@ -398,7 +424,7 @@ struct GeoMeanLogOps {
 //   * the CURRENT tick, visited first by both walks, as one record per pool
 //       cur_a = {k, sA = R₁+α}   cur_b = {sB = R₂+β, δmax↑ = k/β − sA}   cur_c = δmax↓ = k/α − sB
 //     (the flipped pool of :289 swaps sA/sB), plus curR = {R₁, R₂}, read only when the tick drains;
-//   * the ticks beyond it as per-direction walk lists of the NON-EMPTY ticks only,
+//   * the ticks beyond it as per-direction walk lists of the NON-EMPTY ticks only, one 64-byte record per tick
 //       ks = {k, s_in}   dt = {δmax, s_out}   rout = R_out     ("in"/"out" already flipped).
 // A sweep then costs one division and one or two square roots per visited tick instead of six
 // square roots and four divisions, empty ticks cost nothing, and a pool that trades inside its
@@ -457,15 +483,16 @@ struct UniV3Ops {
     template <bool FAST>
     __device__ __forceinline__ void list_tick(int e, double price, double yp, double& d, double& l) const
     {
-        const double2 ks = p.ks[e];
+        const TickRec& rec = p.ticks[e];
+        const double2 ks = rec.ks, dt = rec.dt;                    // one 64-byte line per visited tick, requested at once
+        const double rout = rec.rout;
         const double dd = (FAST ? fast_sqrt(div_by(ks.x, price, yp)) : sqrt(ks.x / price)) - ks.y;   // :323
         d = 0.0;
         l = 0.0;                                                   // :325-327
         if (dd > 0) {
-            const double2 dt = p.dt[e];
             if (dd >= dt.x) {                                      // :330-332
                 d = dt.x;
-                l = p.rout[e];
+                l = rout;
             } else {
                 l = dt.y - (FAST ? fast_sqrt(price * ks.x) : sqrt(price * ks.x));   // :334
                 d = dd;
@@ -513,31 +540,26 @@ struct UniV3Ops {
         }
         return true;
     }
-    template <bool FAST>
-    __device__ __forceinline__ void tail(bool up, double g, double yg, double sd, double sl, Trade& t) const
-    {
-        const double d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;
-        if (up) { t.d1 = d; t.l2 = sl; }                                   // :366-372
-        else { t.d2 = d; t.l1 = sl; }                                      // :386-391
-    }
-
     // Lane-per-pool walk (segments whose walk lists are short, e.g. every BoundedProduct pool).
     template <bool FAST>
-    __device__ __forceinline__ void solve(const Raw& r, const Px& px, Trade& t) const
+    __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
     {
         bool up;
         double g, yg, price, yp, sd, sl;
-        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl)) return;
+        d = l = 0.0;
+        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl)) return t.d1 != t.d1 ? kDirBoth : kDirNone;   // (NaN price: t is all-NaN)
         const int begin = up ? r.walk.x : r.walk.z;
         const int count = up ? r.walk.y : r.walk.w;
         for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
-            double d, l;
-            list_tick<FAST>(begin + j, price, yp, d, l);
-            if (d == 0 || l == 0) break;                               // :363-365 (initial is false here)
-            sd += d;
-            sl += l;
+            double dj, lj;
+            list_tick<FAST>(begin + j, price, yp, dj, lj);
+            if (dj == 0 || lj == 0) break;                             // :363-365 (initial is false here)
+            sd += dj;
+            sl += lj;
         }
-        tail<FAST>(up, g, yg, sd, sl, t);
+        d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;             // :366-372 / :386-391
+        l = sl;
+        return up ? kDir1 : kDir2;
     }
 };
 
@@ -555,10 +577,11 @@ struct UniV3CoopOps : UniV3Ops {
     // All 64 lanes must call this together (`valid` = this lane holds a pool).
     static constexpr int kCoopLanes = 4;   // stragglers left in a wavefront before it finishes them together
     template <bool FAST>
-    __device__ __forceinline__ void solve_wave(const Raw& r, bool valid, const Px& px, Trade& t) const
+    __device__ __forceinline__ int solve_wave(const Raw& r, bool valid, const Px& px, double& d_out, double& l_out, Trade& t) const
     {
         const int lane = threadIdx.x & 63;
         t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
+        d_out = l_out = 0.0;
         bool trades = false, up = false, pending = false;
         double g = 1.0, yg = 1.0, price = 1.0, yp = 1.0, sd = 0.0, sl = 0.0;
         int next = 0, remaining = 0;                                   // walk-list cursor of this lane's pool
@@ -614,7 +637,10 @@ struct UniV3CoopOps : UniV3Ops {
                 }
             }
         }
-        if (trades) tail<FAST>(up, g, yg, sd, sl, t);
+        if (!trades) return (valid && t.d1 != t.d1) ? kDirBoth : kDirNone;     // (NaN price: t is all-NaN)
+        d_out = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;                 // :366-372 / :386-391
+        l_out = sl;
+        return up ? kDir1 : kDir2;
     }
 };
 
@@ -625,11 +651,16 @@ struct UniV3CoopOps : UniV3Ops {
 // leave during the sweep instead of in a serial flush of dirty L2 lines at its end (MI355X_MICROARCH.md, boundary row:
 // + B / 6 TB/s for B dirty bytes; measured against plain and non-temporal stores in rounds 1 and 2: -1..-2 us per
 // 1M-pool sweep).
+// The s_nop is part of the store: a VMEM store of more than 8 bytes reads its upper data registers one cycle after
+// issue, and the VALU must not overwrite them in that cycle (gfx9 hazard "VMEM store > 8 bytes followed by a write of
+// the VGPRs holding the write data: 1 wait state").  The compiler inserts that wait state for its own stores; it
+// cannot see through inline asm -- and the values stored here are selects computed right before the next store, so the
+// next v_cndmask may land in the registers of this one (found as 9 % wrong rows in the two-row trade layout).
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_pair(double2* dst, double x, double y)
 {
     d2v val = {x, y};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(val) : "memory");
 }
 
 // One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
@@ -774,10 +805,51 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
             px.dlv = a.need_logv ? L.lv[tok.y] - L.lv[tok.x] : log(px.v2 / px.v1);
     }
     Trade t;
-    if constexpr (Ops::kWaveCooperative) ops.template solve_wave<FAST>(raw, valid, px, t);
-    else ops.template solve<FAST>(raw, px, t);
+    double d, l;
+    int dir;
+    if constexpr (Ops::kWaveCooperative) dir = ops.template solve_wave<FAST>(raw, valid, px, d, l, t);
+    else dir = ops.template solve_dir<FAST>(raw, px, d, l, t);
     if (!valid) return;
     const double v1 = px.v1, v2 = px.v2;
+    // One direction (the common case): the tendered token's bin gets −d, the received token's +l, the dual scalar
+    // l·v_out − d·v_in -- the reference's expressions (src/router.jl:82, :99) with their zero terms dropped: same bits.
+    // A compact trade record needs two values with a clear sign bit; the tiny negative / −0.0 amounts the reference's
+    // tick arithmetic leaves on degenerate UniV3 boundaries (and anything kDirBoth) take the general path below.
+    const bool one = dir == kDir1 || dir == kDir2;
+    const bool plain = one && (!MAT || !a.compact || (__double2hiint(d) | __double2hiint(l)) >= 0);
+    if (plain) {
+        const bool d1 = dir == kDir1;
+        if (MAT) {
+            if (a.compact) {
+                store_pair(a.Delta + i, d1 ? d : -d, l);   // {+Δ₁, Λ₂} or {−Δ₂, Λ₁}: the sign bit carries the direction
+            } else {
+                store_pair(a.Delta + i, d1 ? d : 0.0, d1 ? 0.0 : d);
+                store_pair(a.Lambda + i, d1 ? 0.0 : l, d1 ? l : 0.0);
+            }
+        }
+        acc += l * (d1 ? v2 : v1) - d * (d1 ? v1 : v2);
+        if constexpr (GBINS) {
+            a.gflow[i] = d1 ? make_double2(0.0 - d, l) : make_double2(l, 0.0 - d);
+        } else {
+            const double f_in = 0.0 - d;                       // Λ − Δ of the tendered token
+            if (f_in != 0.0) atomicAdd(&L.my_bins[d1 ? tok.x : tok.y], f_in);   // ds_add_f64
+            if (l != 0.0) atomicAdd(&L.my_bins[d1 ? tok.y : tok.x], l);
+        }
+        return;
+    }
+    if (dir == kDirNone) {
+        if (MAT) {
+            if (a.compact) {
+                store_pair(a.Delta + i, 0.0, 0.0);
+            } else {
+                store_pair(a.Delta + i, 0.0, 0.0);
+                store_pair(a.Lambda + i, 0.0, 0.0);
+            }
+        }
+        if constexpr (GBINS) a.gflow[i] = make_double2(0.0, 0.0);
+        return;
+    }
+    expand_dir(dir, d, l, t);
     if (MAT) {
         if (a.compact) {   // one 16-byte record per pool (see SweepArgs)
             // a record can carry one direction whose two values have a clear sign bit (NaN payloads survive the

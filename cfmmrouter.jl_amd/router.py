@@ -48,8 +48,8 @@ class DeviceBackend:
         self.ctx.find_arb(v)
         return self.ctx.netflows(), self.ctx.dual_value()
 
-    def trades(self):
-        return self.ctx.trades()
+    def trades(self, out=None):
+        return self.ctx.trades(out)
 
     def reload(self, batches):
         """Replace the device pool store (used after update_reserves_)."""

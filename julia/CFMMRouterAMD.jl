@@ -240,6 +240,13 @@ function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxf
     return info[]
 end
 
+# Library options (include/cfmm_amd.h, cfmm_set_option): e.g. set_option!(r, "stop_in_noise", 1) for the noise-floor
+# stop of route_native! (default 0 = the stopping rules of L-BFGS-B 3.0), set_option!(r, "fast_math", 0), ...
+function set_option!(r::AMDRouter, key::AbstractString, value::Integer)
+    check(r.ctx, ccall((:cfmm_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), r.ctx, key, Int64(value)))
+    return nothing
+end
+
 # netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125
 function netflows!(ψ, r::AMDRouter)
     ψ .= r.Ψ

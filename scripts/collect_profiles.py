@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -25,6 +25,8 @@ for name in ("floor.txt", "dist_world1.json", "bench_torchrun_world1_peer.json",
     if os.path.exists(os.path.join(src, name)):
         out = {"floor.txt": "launch_floor.txt"}.get(name, name)
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{out}"))
+if os.path.exists(os.path.join(src, "pmc_extra.json")):
+    shutil.copy(os.path.join(src, "pmc_extra.json"), os.path.join(dst, f"{rnd}_pmc_extra.json"))
 for f in glob.glob(os.path.join(src, "benchfull_*.log")):
     lines = [x for x in open(f) if x.startswith("{")]
     if lines:

@@ -10,9 +10,9 @@ from cfmmrouter_amd import synth
 import bench
 
 name = sys.argv[1]
-desc, n, build = bench.WORKLOADS[name]
-batches = build(0)
-v = synth.sweep_prices(n, seed=1234)
+desc, n, _ = bench.WORKLOADS[name]
+batches = bench.build_market(name, 0, 1, "weak")
+v = bench.sweep_prices_for(name, n)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 v_t = torch.from_numpy(v).to("cuda"); out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
 K = int(os.environ.get("K", "200"))

@@ -1,7 +1,8 @@
 #!/bin/bash
-# One GPU-box session for the judged artefacts: parity tests, bench lines, rocprofv3 kernel stats, PMC traffic.
+# One GPU-box session for the judged artefacts: parity tests, bench lines, rocprofv3 kernel stats, PMC traffic, SQ counters.
 # Every step is bounded.  Outputs go to gpurun_out/ (scratch); scripts/collect_profiles.py copies the
-# summaries into profiles/ (tracked).   usage: [TESTS=1] [FULL="config3 ..."] [PROF="config3 ..."] [PMC="config3"] bash scripts/gpu_round.sh
+# summaries into profiles/ (tracked).
+#   usage: [TESTS=1] [FULL="config3 ..."] [PROF="config3 ..."] [PMC="config3"] [PMCX="config3"] bash scripts/gpu_round.sh
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 if [ -n "$TESTS" ]; then
@@ -18,10 +19,9 @@ cd /tmp && export TMPDIR=/tmp
 for w in $PROF; do
   for mode in warm cold; do
     flag="--no-cold"; [ "$mode" = "cold" ] && flag="--cold-only"
-    # CFMM_AMD_ARMED=0: route!'s pre-armed launches would count the time they wait for the host as kernel time
-    CFMM_AMD_ARMED=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${w}_$mode -o $w -- python $R/bench.py --steps 100 --warmup 10 --no-cpu $flag --workload $w > $R/gpurun_out/prof_${w}_$mode.log 2>&1 < /dev/null
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${w}_$mode -o $w -- python $R/bench.py --steps 100 --warmup 10 --no-cpu $flag --workload $w > $R/gpurun_out/prof_${w}_$mode.log 2>&1 < /dev/null
     f=$(find $R/gpurun_out/prof_${w}_$mode -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && echo "== $w $mode" && head -4 "$f" | cut -c1-200
+    [ -n "$f" ] && echo "== $w $mode" && head -3 "$f" | cut -c1-200
   done
 done
 for w in $PMC; do
@@ -29,6 +29,11 @@ for w in $PMC; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${w}_$c -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmc_${w}_$c.log 2>&1 < /dev/null
   done
 done
+for w in $PMCX; do   # occupancy / stall mix / LDS conflicts / L2 hit rate of the dominant kernels
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/pmcx_${w}_sq -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmcx_${w}_sq.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmcx_${w}_tcc -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmcx_${w}_tcc.log 2>&1 < /dev/null
+done
 cd $R
 [ -n "$PMC" ] && timeout 60 python scripts/pmc_summary.py gpurun_out $PMC < /dev/null
+[ -n "$PMCX" ] && timeout 60 python scripts/pmc_extra_summary.py < /dev/null
 true

@@ -19,7 +19,8 @@ for f in files:
 rows.sort()
 # the last run of consecutive fused sweeps (sweep_multi<false / sweep_kernel<..., false, ...) each followed by a fold
 def fused(n):
-    return ("sweep_multi<false" in n) or ("sweep_kernel<" in n and ", false, 1," in n)
+    import re
+    return ("sweep_multi<false" in n) or re.search(r"sweep_kernel<[^,]+, false,", n) is not None
 evals = []
 i = len(rows) - 1
 while i > 0 and not fused(rows[i - 1][2]):

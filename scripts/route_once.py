@@ -6,8 +6,8 @@ import numpy as np
 import cfmmrouter_amd as cr
 import bench
 name, armed = sys.argv[1], int(sys.argv[2])
-desc, n, build = bench.WORKLOADS[name]
-batches = build(0)
+desc, n, _ = bench.WORKLOADS[name]
+batches = bench.build_market(name, 0, 1, "weak")
 obj = bench.objective_for(name, n)
 v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
 r = cr.Router(obj, batches, n)

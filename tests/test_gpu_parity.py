@@ -661,6 +661,30 @@ def test_full_size_config5_all_rows(consistent):
     _size_independent_checks([bu], D, L, psi, acc, v, n)
 
 
+def test_full_size_univ3_ticks_all_rows():
+    """The multi-tick workload of bench.py (--workload univ3_ticks) at full size: 1M UniV3 pools with ragged ladders of
+    2..64 initialised ticks (17M ticks), swept a few per cent off the price vector they are quoted around, so that most
+    pools walk through several ticks (src/cfmms.jl:339-395): every trade row bit-exact against the CPU restatement."""
+    n = 256
+    bu = synth.univ3_ragged_pools(1_000_000, n, seed=1234)
+    v = synth.sweep_prices(n, seed=1234) * synth.token_price_vector(n, seed=1234)
+    visited = synth.univ3_ticks_visited(bu, v)
+    assert np.mean(visited > 1) > 0.5 and visited.max() >= 16          # a real multi-tick walk, not the 2-tick degenerate case
+    be = cr.DeviceBackend(n, [bu])
+    psi, acc = be.find_arb(v)
+    D, L = be.trades()
+    psi_f, acc_f = be.eval(v)
+    psi_f, acc_f = be.eval(v)                                           # (same tile direction as the materialising sweep)
+    be.close()
+    Do, Lo, psi_o, acc_o = oracle_sweep([bu], n, v, nthreads=_threads())
+    np.testing.assert_array_equal(D, Do)
+    np.testing.assert_array_equal(L, Lo)
+    assert rel_to_max(psi, psi_o) <= REDUCE_TOL and abs(acc - acc_o) <= REDUCE_TOL * abs(acc_o)
+    np.testing.assert_array_equal(psi_f, psi)
+    assert np.all(D[visited == 0] == 0) and np.all(L[visited == 0] == 0)   # pools inside their no-arbitrage band
+    assert np.count_nonzero(D.sum(axis=1) > 0) > 0.9 * np.count_nonzero(visited > 0)
+
+
 # ---- the reference's optimality predicate (test/cfmms.jl:3-22) on DEVICE trades ---------------------
 
 SQRT_EPS = math.sqrt(np.finfo(float).eps)

@@ -12,6 +12,7 @@ import cfmmrouter_amd as cr
 from cfmmrouter_amd import synth
 from cfmmrouter_amd._lib import KIND_PRODUCT, LIB_PATH
 from oracle import cfmm_oracle as orc
+from helpers import oracle_sweep
 from helpers import OracleBackend, oracle_objective, oracle_poolset, rel_to_max
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -330,3 +331,19 @@ def test_bench_self_spawns_one_rank_per_gpu(tmp_path):
     if not torch.cuda.is_available():
         assert r.returncode != 0
         assert "[rank 0/2] bench.py needs an MI355X" in out and "[rank 1/2] bench.py needs an MI355X" in out
+
+
+def test_univ3_ticks_visited_bookkeeping_matches_the_oracle_walk():
+    """bench.py prices a multi-tick UniV3 sweep by the ticks the walk VISITS (32 B + 16 B per tick): the
+    bookkeeping function must agree with what find_arb! (src/cfmms.jl:339-395, CPU restatement) does -- a pool counted
+    as idle trades nothing, and a pool that trades through k ticks has at least k - 1 of them drained to their bound."""
+    n = 24
+    b = synth.univ3_ragged_pools(4000, n, seed=5)
+    v = synth.sweep_prices(n, seed=6) * synth.token_price_vector(n, seed=5)
+    vis = synth.univ3_ticks_visited(b, v)
+    D, L, _, _ = oracle_sweep([b], n, v)
+    assert np.all(D[vis == 0] == 0) and np.all(L[vis == 0] == 0)
+    assert np.mean(vis > 1) > 0.3 and vis.max() <= np.diff(b.tick_off).max()
+    shard = synth.univ3_ragged_pools(1000, n, seed=5, first=3000)       # shards regenerate the same pools
+    np.testing.assert_array_equal(shard.lower_ticks, b.slice(3000, 4000).lower_ticks)
+    np.testing.assert_array_equal(shard.liquidity, b.slice(3000, 4000).liquidity)
