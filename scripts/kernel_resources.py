@@ -27,28 +27,17 @@ for b in blocks:
 for dem, v, s_, sc, lds, occ in sorted(rows):
     print(f"{v:5d} {s_:5d} {sc:8d} {lds:12d} {occ:11d}  {dem}")
 
-# instruction mix of the two tile loops of sweep_kernel<ProductOps, false, 1024> (fused evaluation)
+# instruction classes of the two fused ProductTwoCoin kernels' code (whole kernel: staging, BOTH tile loops -- the one on the
+# fast arithmetic and the one on the compiler's division / square-root sequences -- and the epilogue)
 asm = open(os.path.join(tmp, "sweep_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-m = re.search(r"^_ZN4cfmm12sweep_kernelINS_10ProductOpsELb0ELi1024ELb0EEEvT_NS_9SweepArgsE:.*?s_endpgm", asm, flags=re.S | re.M)
-if m:
-    body = m.group(0).split("\n")
-    # the kernel holds two copies of the tile loop: the one with v_div_scale (compiler sequences) and the one without
-    loops, cur = [], None
-    for line in body:
-        if "Loop Header: Depth=1" in line and cur is not None and len(cur) > 150:
-            loops.append(cur)
-        if "Loop Header: Depth=1" in line:
-            cur = []
-        elif cur is not None:
-            cur.append(line)
-    if cur and len(cur) > 150:
-        loops.append(cur)
-    print("\n# tile loops of sweep_kernel<ProductOps, false, 1024> (one pool per lane per trip; instruction counts of the loop bodies,")
-    print("# all paths -- the rare both-directions fallback included)")
-    for lp in loops:
-        ins = [l.split()[0] for l in lp if l.startswith("\t") and not l.strip().startswith(";") and not l.strip().startswith(".")]
-        n = len(ins)
-        cnt = lambda pat: sum(1 for i in ins if re.match(pat, i))
-        kind = "compiler sequences (fast_math off / operands outside the window)" if cnt(r"v_div_scale") else "fast arithmetic"
-        print(f"  {kind}: {n} instructions; f64 VALU {cnt(r'v_.*_f64')}, v_div_scale/fmas/fixup {cnt(r'v_div_')}, v_rcp/v_rsq {cnt(r'v_r(cp|sq)_f64')}, "
-              f"v_cndmask {cnt(r'v_cndmask')}, ds_* {cnt(r'ds_')}, global_* {cnt(r'global_')}, s_* {cnt(r's_')}")
+print("\n# static instruction counts (whole kernel code)")
+for sym, label in (("_ZN4cfmm12sweep_kernelINS_10ProductOpsELb0ELi1024ELb0EEEvT_NS_9SweepArgsE", "sweep_kernel<ProductOps, false, 1024, false>"),
+                   ("_ZN4cfmm12sweep_kernelINS_13GeoMeanLogOpsELb0ELi1024ELb0EEEvT_NS_9SweepArgsE", "sweep_kernel<GeoMeanLogOps, false, 1024, false>"),
+                   ("_ZN4cfmm12sweep_kernelINS_8UniV3OpsELb0ELi1024ELb0EEEvT_NS_9SweepArgsE", "sweep_kernel<UniV3Ops, false, 1024, false>")):
+    m = re.search(r"^" + sym + r":.*?s_endpgm", asm, flags=re.S | re.M)
+    if not m:
+        continue
+    ins = [l.split()[0] for l in m.group(0).split("\n") if l.startswith("\t") and not l.strip().startswith(";") and not l.strip().startswith(".")]
+    cnt = lambda pat: sum(1 for i in ins if re.match(pat, i))
+    print(f"  {label}: {len(ins)} instructions; f64 VALU {cnt(r'v_.*_f64')}, of them v_div_scale/fmas/fixup {cnt(r'v_div_')} and "
+          f"v_rcp/v_rsq/v_sqrt {cnt(r'v_(rcp|rsq|sqrt)_f64')}; v_cndmask {cnt(r'v_cndmask')}, ds_* {cnt(r'ds_')}, global_* {cnt(r'global_')}, s_* {cnt(r's_')}")
