@@ -209,7 +209,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
     struct { const char* name; int64_t* slot; } table[] = {
         {"max_grid", &c->opt_max_grid}, {"block", &c->opt_block}, {"bin_copies", &c->opt_bin_copies},
         {"time_kernels", &c->opt_time_kernels}, {"geomean_exact", &c->opt_geomean_exact},
-        {"fuse_segments", &c->opt_fuse_segments}, {"zero_copy", &c->opt_zero_copy}, {"univ3_coop", &c->opt_univ3_coop},
+        {"fuse_segments", &c->opt_fuse_segments}, {"zero_copy", &c->opt_zero_copy},
         {"alternate", &c->opt_alternate}, {"pack", &c->opt_pack}, {"compact_trades", &c->opt_compact_trades},
         {"fast_math", &c->opt_fast_math}, {"armed", &c->opt_armed}, {"arm_timeout_ms", &c->opt_arm_timeout_ms},
         {"cost_geomean", &c->opt_cost_geomean}, {"cost_univ3", &c->opt_cost_univ3}, {"host_flag", &c->opt_host_flag},
@@ -238,7 +238,7 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
             if (rc != CFMM_OK) return fail(c, rc, "%s", child->err.c_str());
         }
     if (slot == &c->opt_max_grid || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
-        slot == &c->opt_geomean_exact || slot == &c->opt_univ3_coop || slot == &c->opt_pack ||
+        slot == &c->opt_geomean_exact || slot == &c->opt_pack ||
         slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
         c->geometry_dirty = true;
     return CFMM_OK;

@@ -59,7 +59,7 @@ int64_t family_cost(const cfmm_ctx* c, const Segment& s)
     switch (s.kind) {
     case CFMM_KIND_PRODUCT: return 10;
     case CFMM_KIND_GEOMEAN: return c->opt_cost_geomean;
-    default: return c->opt_cost_univ3 + (s.m > 0 && s.n_ticks_total / s.m > 2 ? 2 * (s.n_ticks_total / s.m) : 0);   // deeper ladders walk longer
+    default: return c->opt_cost_univ3 + (s.m > 0 && s.n_ticks_total / s.m > 2 ? 6 : 0);   // multi-tick ladders: a threshold scan + one more record
     }
 }
 
@@ -194,9 +194,6 @@ int ensure_geometry(cfmm_ctx* c)
         plan_segment(c, s);
         s.trade_off = trades;
         trades += s.m;
-        // the fused kernel always carries the wavefront-cooperative UniV3 walk; "univ3_coop" = 0 (lane-per-pool
-        // walks only) is honoured by sweeping such routers with per-segment launches
-        if (s.kind == CFMM_KIND_UNIV3 && c->opt_univ3_coop == 0) fusable = false;
         any_big = any_big || s.block == kBigBlock;
     }
     c->groups.clear();
@@ -362,8 +359,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             return GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, s.pk, gbase_of(s)};
         };
         auto univ3_of = [&](const Segment& s) {
-            return UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ticks,
-                              c->opt_univ3_coop < 0 ? s.deep : (int)(c->opt_univ3_coop != 0), s.has_walk, s.cp, s.pk, gbase_of(s)};
+            return UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ticks, s.thr, s.has_walk, s.cp, s.pk, gbase_of(s)};
         };
         hipError_t e = hipSuccess;
         if (g.multi) {

@@ -87,6 +87,58 @@ int check_two_coin(cfmm_ctx* c, int64_t m, const double* R, const double* gamma,
     return CFMM_OK;
 }
 
+// Largest price P for which find_arb_pos (src/cfmms.jl:321-337) DRAINS a tick with the prepared constants k, s_in = R_in + α,
+// δmax: dd = sqrt(k/P) − s_in is > 0 and >= δmax.  The test is monotone in P (IEEE division, square root and subtraction are
+// correctly rounded, hence monotone), so there is exactly one such double; it is found on the test ITSELF -- gallop from the
+// algebraic boundary k/(s_in + δmax)², then bisect on the bit patterns -- so that `price <= T` on the device is the
+// reference's floating-point decision, not an approximation of it.  0: the tick never drains for a positive price.
+double drain_threshold(double k, double s_in, double dmax)
+{
+    auto drains = [&](double P) {
+        const double dd = std::sqrt(k / P) - s_in;
+        return dd > 0 && dd >= dmax;
+    };
+    auto bits = [](double x) { int64_t b; std::memcpy(&b, &x, sizeof b); return b; };
+    auto from = [](int64_t b) { double x; std::memcpy(&x, &b, sizeof x); return x; };
+    const int64_t lo_lim = bits(0x1p-1000), hi_lim = bits(0x1p1000);
+    double c0 = k / ((s_in + dmax) * (s_in + dmax));
+    if (!(c0 > 0x1p-1000)) c0 = 0x1p-1000;     // (also catches NaN)
+    if (!(c0 < 0x1p1000)) c0 = 0x1p1000;
+    int64_t lo, hi;                            // drains(lo), !drains(hi)
+    const int64_t cb = bits(c0);
+    if (drains(c0)) {
+        lo = cb;
+        for (int64_t step = 1;; step *= 2) {
+            const int64_t nb = lo + step;
+            if (nb >= hi_lim) {
+                if (drains(from(hi_lim))) return from(hi_lim);
+                hi = hi_lim;
+                break;
+            }
+            if (!drains(from(nb))) { hi = nb; break; }
+            lo = nb;
+        }
+    } else {
+        hi = cb;
+        for (int64_t step = 1;; step *= 2) {
+            const int64_t nb = hi - step;
+            if (nb <= lo_lim) {
+                if (!drains(from(lo_lim))) return 0.0;
+                lo = lo_lim;
+                break;
+            }
+            if (drains(from(nb))) { lo = nb; break; }
+            hi = nb;
+        }
+    }
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (drains(from(mid))) lo = mid;
+        else hi = mid;
+    }
+    return from(lo);
+}
+
 int add_segment_common(cfmm_ctx* c, Segment&& s, const int32_t* Ai)
 {
     if (s.m == 0) {   // an empty batch contributes no pools, no trades and no partial rows: not stored
@@ -110,7 +162,7 @@ void free_segment(Segment& s)
     (void)hipFree(s.R); (void)hipFree(s.w); (void)hipFree(s.gamma); (void)hipFree(s.Ai);
     (void)hipFree(s.eta); (void)hipFree(s.lR); (void)hipFree(s.pk);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
-    (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ticks);
+    (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ticks); (void)hipFree(s.thr);
     s = Segment{};
 }
 
@@ -119,14 +171,14 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
                 const int64_t* tick_off, const double* lower_ticks, const double* liquidity)
 {
     const int64_t T = m > 0 ? tick_off[m] : 0;
-    if (T < 0 || 2 * T > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
+    if (T < 0 || 2 * (T + 2 * m) > (int64_t)0x3fffffff) return fail(c, CFMM_ERR_UNSUPPORTED, "too many ticks in one segment");
     std::vector<double2> pg((size_t)m), cur_a((size_t)m), cur_b((size_t)m), curR((size_t)m);
     std::vector<double> cur_c((size_t)m);
     std::vector<TickRec> ticks;
     std::vector<int4> walk((size_t)m);
     int longest = 0;
     bool fast = true;   // every operand of the sweep's divisions / square roots inside the fast window (sweep.h)
-    ticks.reserve((size_t)T);
+    ticks.reserve((size_t)T + 2 * (size_t)m);
     for (int64_t i = 0; i < m; ++i) {
         const int64_t o = tick_off[i], nt = tick_off[i + 1] - o;
         if (nt < 1) return fail(c, CFMM_ERR_INVALID_ARG, "pool %lld: needs at least one tick", (long long)i);
@@ -182,28 +234,42 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
             curR[(size_t)i] = make_double2(R1, R2);
             if (k == 0) { cur_b[(size_t)i].y = 0.0; cur_c[(size_t)i] = 0.0; } // 0/0: never read (k == 0 is skipped)
         }
+        // Walk lists (UniV3Ops::solve_dir): the non-empty ticks beyond the current one, in walk order; every record also
+        // carries the sums of the drained ticks BEFORE it, starting from what the current tick contributes when it drains
+        // ({δmax, R_out}; nothing if it is empty) and accumulated with the walk's own additions; one closing record per
+        // list carries the sums of the whole list.
+        double kc, alc, bec, R1c, R2c;
+        at_tick(ct, kc, alc, bec, R1c, R2c);
         int4 w;
         w.x = (int)ticks.size();
         int cnt = 0;
+        double2 run = kc != 0 ? make_double2(cur_b[(size_t)i].y, R2c) : make_double2(0.0, 0.0);   // price falling: δmax↑, R₂ out
         for (int64_t idx = ct + 1; idx <= nt; ++idx) {        // get_upper_pools beyond the current tick, :316
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;                             // is_empty_pool, :288
-            const double s_in = R1 + al;
-            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(k / be - s_in, R2 + be), R2, {0.0, 0.0, 0.0}});   // :329, :334
+            const double s_in = R1 + al, dmax = k / be - s_in;
+            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(dmax, R2 + be), R2, 0.0, run});   // :329, :334
+            run.x += dmax;
+            run.y += R2;
             ++cnt;
         }
+        ticks.push_back(TickRec{make_double2(0.0, 0.0), make_double2(0.0, 0.0), 0.0, 1.0, run});           // closing record (pad = 1 marks it)
         w.y = cnt;
         w.z = (int)ticks.size();
         cnt = 0;
+        run = kc != 0 ? make_double2(cur_c[(size_t)i], R1c) : make_double2(0.0, 0.0);                      // price rising (flipped pool, :289)
         for (int64_t idx = ct - 1; idx >= 1; --idx) {         // flip_sides.(get_lower_pools), :317,:289
             double k, al, be, R1, R2;
             at_tick(idx, k, al, be, R1, R2);
             if (k == 0) continue;
-            const double s_in = R2 + be;
-            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(k / al - s_in, R1 + al), R1, {0.0, 0.0, 0.0}});
+            const double s_in = R2 + be, dmax = k / al - s_in;
+            ticks.push_back(TickRec{make_double2(k, s_in), make_double2(dmax, R1 + al), R1, 0.0, run});
+            run.x += dmax;
+            run.y += R1;
             ++cnt;
         }
+        ticks.push_back(TickRec{make_double2(0.0, 0.0), make_double2(0.0, 0.0), 0.0, 1.0, run});
         w.w = cnt;
         longest = std::max(longest, std::max(w.y, w.w));
         walk[(size_t)i] = w;
@@ -213,7 +279,25 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
     s.kind = CFMM_KIND_UNIV3;
     s.m = m;
     s.n_ticks_total = T;
-    s.deep = longest > 8 ? 1 : 0; // short ladders: a lane walks its own pool; long: the wavefront helps
+    // drain thresholds of all records (the closing records and ticks that end the walk when reached -- δmax = 0 or R_out = 0,
+    // :363-365 -- get 0 = "never"), a few bisection steps each: spread over the host's cores
+    std::vector<double> thr(ticks.size(), 0.0);
+    {
+        const size_t nrec = ticks.size();
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned nthr = nrec > 65536 ? hw : 1;
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t e = lo; e < hi; ++e) {
+                const TickRec& r = ticks[e];
+                if (r.pad != 0.0 || r.dt.x == 0.0 || r.rout == 0.0) continue;
+                thr[e] = drain_threshold(r.ks.x, r.ks.y, r.dt.x);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work, nrec * t / nthr, nrec * (t + 1) / nthr);
+        work(0, nrec / nthr);
+        for (auto& th : pool) th.join();
+    }
     s.has_walk = longest > 0 ? 1 : 0;
     s.fast_ok = fast ? 1 : 0;
     int rc;
@@ -221,6 +305,7 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
         (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
         (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
         (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ticks, ticks.data(), ticks.size())) ||
+        (rc = upload(c, &s.thr, thr.data(), thr.size())) ||
         (rc = upload(c, &s.cp, current_price, (size_t)m)) || (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;

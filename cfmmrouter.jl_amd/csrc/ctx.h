@@ -34,7 +34,6 @@ struct Segment {
     int64_t m = 0;
     int64_t trade_off = 0; // first row of this segment in the trade buffers
     int64_t n_ticks_total = 0;
-    int deep = 0; // univ3: longest walk list exceeds kDeepWalk -> wavefront-cooperative kernel
     int fast_ok = 0; // every constant the sweep divides by / takes roots of lies in [2^-kFastExp, 2^kFastExp] (sweep.h)
     // device arrays (owned)
     double2* R = nullptr;
@@ -52,6 +51,7 @@ struct Segment {
     double2* curR = nullptr;
     int4* walk = nullptr;
     TickRec* ticks = nullptr;   // univ3: walk lists (sweep.h TickRec)
+    double* thr = nullptr;      // univ3: drain thresholds, one per record
     // launch geometry (decided by ensure_geometry)
     int block = kMidBlock;
     int grid = 0;
@@ -177,7 +177,6 @@ struct cfmm_ctx {
     int64_t opt_time_kernels = 0;
     int64_t opt_geomean_exact = 0; // 1: pow-based reference-order forms instead of log-space
     int64_t opt_fuse_segments = 1; // 1: sweep all pool families in one launch (sweep_multi)
-    int64_t opt_univ3_coop = -1;   // -1 auto (by walk-list length), 0 lane-per-pool only, 1 wavefront-cooperative
     int64_t opt_zero_copy = 1;     // 1: host-pointer calls read v / receive Ψ through mapped pinned memory
     int64_t opt_cost_geomean = 10; // cost of a GeometricMean / UniV3 evaluation in tenths of a ProductTwoCoin one (10 = blocks in
     int64_t opt_cost_univ3 = 10;   // proportion to pool counts)

@@ -59,7 +59,9 @@ struct alignas(64) TickRec {
     double2 ks;                  // {k, R_in + alpha_in}
     double2 dt;                  // {delta_max, R_out + beta_out}
     double rout;                 // R_out
-    double pad[3];
+    double pad;
+    double2 psum;                // {Σδ, Σλ} of the current tick and of every list tick BEFORE this one, all drained, summed in
+                                 // walk order (UniV3Ops::solve_dir); every list is closed by a record that carries only this
 };
 struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constants (see UniV3Ops)
     const double2* pg;           // [m] {current_price, gamma}
@@ -69,8 +71,9 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     const double* cur_c;         // [m] current tick  k/alpha - (R2+beta)
     const double2* curR;         // [m] current tick {R1, R2}
     const int4* walk;            // [m] ticks beyond the current one: {up_begin, up_count, lo_begin, lo_count}
-    const TickRec* ticks;        // [W] the walk lists: per pool the non-empty ticks above, then below, its current one
-    int deep;                    // 1: some walk list is long -> wavefront-cooperative kernel (UniV3CoopOps)
+    const TickRec* ticks;        // [W] the walk lists: per pool the non-empty ticks above, then below, its current one, each
+                                 //     list closed by one extra record (psum of the whole list)
+    const double* thr;           // [W] per record: the largest price at which the walk drains that tick (0: never / closing record)
     int has_walk;                // 0: no pool of the segment has a tick beyond its current one (every BoundedProduct
                                  //    pool): the walk spans are not even loaded
     const double* cp;            // [m] current_price alone, read with pk instead of pg + Ai (packed records)

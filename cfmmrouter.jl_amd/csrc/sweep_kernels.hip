@@ -5,7 +5,7 @@
 //   find_arb!(r::Router, v)            src/router.jl:38-42    -> sweep_kernel / sweep_multi (sweep_body)
 //   find_arb!(.., ::ProductTwoCoin)    src/cfmms.jl:125-140   -> ProductOps::solve
 //   find_arb!(.., ::GeometricMeanTwoCoin) src/cfmms.jl:180-196 -> GeoMeanLogOps::solve (default), GeoMeanOps::solve
-//   find_arb!(.., ::UniV3) + helpers   src/cfmms.jl:294-395   -> UniV3Ops::solve, UniV3CoopOps::solve_wave
+//   find_arb!(.., ::UniV3) + helpers   src/cfmms.jl:294-395   -> UniV3Ops::solve_dir
 //   acc loop of fn                     src/router.jl:79-83    -> per-lane acc + wave shuffles
 //   scatter loop of g! / netflows!     src/router.jl:98-100, :111-119 -> LDS bins + reduce_partials
 //                                      (n_tokens > 8192: flow array + gather_chunks / token_fold)
@@ -143,7 +143,6 @@ __device__ __forceinline__ void expand_dir(int dir, double d, double l, Trade& t
 // taken apart in resolve(), after the tile's data has arrived.
 
 struct ProductOps {
-    static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 R;
@@ -260,7 +259,6 @@ __device__ __forceinline__ double geom_arb_lambda(double m, double r1, double r2
 }
 
 struct GeoMeanOps {
-    static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 R, w;
@@ -330,7 +328,6 @@ struct GeoMeanOps {
 // the reserve scale (asserted at 1e-12 in tests/test_gpu_parity.py); unlike r2^η in the reference,
 // nothing here can overflow.
 struct GeoMeanLogOps {
-    static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = true;
     struct Raw {
         double2 R, Q;
@@ -425,13 +422,13 @@ struct GeoMeanLogOps {
 //       cur_a = {k, sA = R₁+α}   cur_b = {sB = R₂+β, δmax↑ = k/β − sA}   cur_c = δmax↓ = k/α − sB
 //     (the flipped pool of :289 swaps sA/sB), plus curR = {R₁, R₂}, read only when the tick drains;
 //   * the ticks beyond it as per-direction walk lists of the NON-EMPTY ticks only, one 64-byte record per tick
-//       ks = {k, s_in}   dt = {δmax, s_out}   rout = R_out     ("in"/"out" already flipped).
-// A sweep then costs one division and one or two square roots per visited tick instead of six
-// square roots and four divisions, empty ticks cost nothing, and a pool that trades inside its
+//       ks = {k, s_in}   dt = {δmax, s_out}   rout = R_out   psum = sums of the drained ticks before it
+//     ("in"/"out" already flipped), and the ticks' drain thresholds as a contiguous array (solve_dir).
+// A sweep then costs one division and one or two square roots for the current tick and for the one tick the walk ends
+// in, whatever the number of ticks in between, empty ticks cost nothing, and a pool that trades inside its
 // current tick (the common case; every BoundedProduct pool) touches only coalesced per-pool
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
-    static constexpr bool kWaveCooperative = false;
     static constexpr bool kNeedsLogPrices = false;
     struct Raw {
         double2 pg, ca, cb;   // pg = {current_price, γ}
@@ -481,9 +478,8 @@ struct UniV3Ops {
 
     // find_arb_pos (:321-337) on one prepared walk-list entry; yp = rcp_refined(price) (FAST)
     template <bool FAST>
-    __device__ __forceinline__ void list_tick(int e, double price, double yp, double& d, double& l) const
+    __device__ __forceinline__ void list_tick(const TickRec& rec, double price, double yp, double& d, double& l) const
     {
-        const TickRec& rec = p.ticks[e];
         const double2 ks = rec.ks, dt = rec.dt;                    // one 64-byte line per visited tick, requested at once
         const double rout = rec.rout;
         const double dd = (FAST ? fast_sqrt(div_by(ks.x, price, yp)) : sqrt(ks.x / price)) - ks.y;   // :323
@@ -501,10 +497,13 @@ struct UniV3Ops {
     }
 
     // The part of find_arb! before the walk lists (:340-361 / :381 and the current tick): block-uniformly FAST or not.
-    // Returns false when the pool does not trade (or the price is NaN: t is then all-NaN).
+    // Returns false when the pool does not trade (or the price is NaN: t is then all-NaN).  cur: what the current tick
+    // did -- kCurEmpty (no liquidity: contributes nothing, the walk goes on, :355-358), kCurPartial ({sd, sl} set: the
+    // walk ends in this tick), kCurDrained (contributes {δmax, R_out}: not loaded here, see solve_dir).
+    static constexpr int kCurEmpty = 0, kCurPartial = 1, kCurDrained = 2;
     template <bool FAST>
     __device__ __forceinline__ bool head(const Raw& r, const Px& px, Trade& t, bool& up, double& g, double& yg, double& price,
-                                         double& yp, double& sd, double& sl) const
+                                         double& yp, double& sd, double& sl, int& cur) const
     {
         const double cp = r.pg.x;
         g = r.pg.y;
@@ -515,6 +514,7 @@ struct UniV3Ops {
         up = false;
         price = 1.0;
         yp = 1.0;
+        cur = kCurEmpty;
         if (pr != pr) { t.d1 = t.d2 = t.l1 = t.l2 = pr; return false; }   // NaN prices propagate instead of "no trade"
         if (g * cp <= pr && pr <= (FAST ? div_by(cp, g, yg) : cp / g)) return false;   // :347-349
         up = pr < g * cp;                                                  // :351
@@ -527,11 +527,10 @@ struct UniV3Ops {
             const double s_in = up ? r.ca.y : r.cb.x, s_out = up ? r.cb.x : r.ca.y;
             const double dmax = up ? r.cb.y : r.cc;
             const double dd = (FAST ? fast_sqrt(div_by(k0, price, yp)) : sqrt(k0 / price)) - s_in;   // :323
+            cur = kCurPartial;
             if (dd > 0) {                                                  // :325-327
                 if (dd >= dmax) {                                          // :330-332
-                    const double2 R = p.curR[r.i];
-                    sd = dmax;
-                    sl = up ? R.y : R.x;
+                    cur = kCurDrained;
                 } else {
                     sl = s_out - (FAST ? fast_sqrt(price * k0) : sqrt(price * k0));   // :334
                     sd = dd;
@@ -540,106 +539,55 @@ struct UniV3Ops {
         }
         return true;
     }
-    // Lane-per-pool walk (segments whose walk lists are short, e.g. every BoundedProduct pool).
+
+    // The walk (:353-365 / :375-385).  The reference visits tick after tick; every tick it DRAINS contributes the
+    // v-independent pair {δmax, R_out}, and whether it drains one is a monotone test on the price: sqrt(k/price) − s_in
+    // > 0 and >= δmax holds for every price up to a threshold T and for none above it (division, square root and
+    // subtraction are correctly rounded, hence monotone).  So the upload stores, per walk list in walk order,
+    //   * the thresholds T_j CONTIGUOUSLY (p.thr: 8 ticks per 64-byte line; found by bisection on the reference's own
+    //     floating-point test, so `price <= T_j` IS that test), a 0 closing every list, and
+    //   * in tick j's record the sums {Σδ, Σλ} of everything BEFORE it -- current tick and ticks 0..j−1 all drained --
+    //     accumulated in the walk's order with the walk's operations (same bits as walking), plus a closing record
+    //     per list that carries the sums of the whole list.
+    // A pool whose current tick drains (or is empty) then costs one scan of its thresholds and ONE record, however deep
+    // it walks, instead of one scattered 64-byte line per visited tick; from the first tick that is not drained the
+    // reference's tick-by-tick evaluation takes over (one partially filled tick, normally), and it goes on to the
+    // following tick only inside a 2^-40 band around that tick's threshold -- outside it the next tick cannot be
+    // entered: its s_in is sqrt(k/p⁺) with p⁺ <= this tick's far boundary < price, and rounding is monotone.  A pool
+    // that ends inside its current tick (kCurPartial) runs the plain walk (it stops at the first list tick).
     template <bool FAST>
     __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
     {
         bool up;
+        int cur;
         double g, yg, price, yp, sd, sl;
         d = l = 0.0;
-        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl)) return t.d1 != t.d1 ? kDirBoth : kDirNone;   // (NaN price: t is all-NaN)
+        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl, cur)) return t.d1 != t.d1 ? kDirBoth : kDirNone;   // (NaN price: t is all-NaN)
         const int begin = up ? r.walk.x : r.walk.z;
         const int count = up ? r.walk.y : r.walk.w;
-        for (int j = 0; j < count; ++j) {                              // :353 / :375, empty ticks elided
+        int j = 0;
+        const bool jump = cur != kCurPartial && count > 0;
+        if (jump) {
+            const double* T = p.thr + begin;
+            while (j < count && price <= T[j]) ++j;                        // ticks 0..j−1 drain
+            const double2 before = p.ticks[begin + j].psum;               // (j == count: the list's closing record)
+            sd = before.x;
+            sl = before.y;
+        } else if (cur == kCurDrained) {
+            const double2 R = p.curR[r.i];                                 // no list in this direction: the current tick alone
+            sd = up ? r.cb.y : r.cc;
+            sl = up ? R.y : R.x;
+        }
+        for (; j < count; ++j) {                                           // :353 / :375, empty ticks elided
             double dj, lj;
-            list_tick<FAST>(begin + j, price, yp, dj, lj);
-            if (dj == 0 || lj == 0) break;                             // :363-365 (initial is false here)
+            list_tick<FAST>(p.ticks[begin + j], price, yp, dj, lj);
+            if (dj == 0 || lj == 0) break;                                 // :363-365 (initial is false here)
             sd += dj;
             sl += lj;
+            if (jump && price > p.thr[begin + j] * (1.0 + 0x1p-40)) break;   // the next tick cannot be entered (see above)
         }
-        d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;             // :366-372 / :386-391
+        d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;                 // :366-372 / :386-391
         l = sl;
-        return up ? kDir1 : kDir2;
-    }
-};
-
-// The same family for segments with long walk lists (deep tick ladders).
-struct UniV3CoopOps : UniV3Ops {
-    static constexpr bool kWaveCooperative = true;
-
-    // One lane per pool while most lanes of the wavefront are still walking; the last few
-    // stragglers (pools that walk much deeper than their neighbours) are finished by the WHOLE
-    // wavefront: 64 ticks are evaluated at once (each tick's (δ, λ) depends only on the price), a
-    // ballot finds the first tick that stops the walk (:363-365), and the owning lane adds the
-    // ticks before it in walk order (v_readlane), so the sums keep the reference's rounding.
-    // Measured (scripts/deep_walk.py): when EVERY pool of a wavefront walks deep, lane-per-pool is
-    // the faster form (all 64 lanes busy); cooperation pays for the sparse deep walks.
-    // All 64 lanes must call this together (`valid` = this lane holds a pool).
-    static constexpr int kCoopLanes = 4;   // stragglers left in a wavefront before it finishes them together
-    template <bool FAST>
-    __device__ __forceinline__ int solve_wave(const Raw& r, bool valid, const Px& px, double& d_out, double& l_out, Trade& t) const
-    {
-        const int lane = threadIdx.x & 63;
-        t.d1 = t.d2 = t.l1 = t.l2 = 0.0;
-        d_out = l_out = 0.0;
-        bool trades = false, up = false, pending = false;
-        double g = 1.0, yg = 1.0, price = 1.0, yp = 1.0, sd = 0.0, sl = 0.0;
-        int next = 0, remaining = 0;                                   // walk-list cursor of this lane's pool
-        if (valid) {
-            trades = head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl);
-            if (trades) {
-                next = up ? r.walk.x : r.walk.z;
-                remaining = up ? r.walk.y : r.walk.w;
-                pending = remaining > 0;
-            }
-        }
-        // Walk the lists in lockstep, one tick per lane per trip, while many lanes are still
-        // walking (that IS the parallel form).  Once only a few stragglers are left -- lanes
-        // whose pools walk much deeper than their neighbours' -- the whole wavefront finishes them:
-        // 64 ticks per step instead of one dependent load after another in an almost empty wave.
-        for (;;) {
-            unsigned long long todo = __ballot(pending);
-            if (!todo) break;
-            if (__popcll(todo) <= kCoopLanes) {
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    const int first = __shfl(next, src, 64), count = __shfl(remaining, src, 64);
-                    const double pr_src = __shfl(price, src, 64), yp_src = __shfl(yp, src, 64);
-                    bool stopped = false;
-                    for (int base = 0; base < count && !stopped; base += 64) {
-                        const int idx = base + lane;
-                        const bool in = idx < count;
-                        double d = 0.0, l = 0.0;
-                        if (in) list_tick<FAST>(first + idx, pr_src, yp_src, d, l);
-                        const unsigned long long stop = __ballot(in && (d == 0 || l == 0));
-                        const int batch = count - base < 64 ? count - base : 64;
-                        const int upto = stop ? __ffsll((long long)stop) - 1 : batch;
-                        for (int k = 0; k < upto; ++k) {               // walk order, owner lane accumulates
-                            const double dk = __shfl(d, k, 64), lk = __shfl(l, k, 64);
-                            if (lane == src) { sd += dk; sl += lk; }
-                        }
-                        stopped = stop != 0;
-                    }
-                    todo &= todo - 1;
-                }
-                break;
-            }
-            if (pending) {                                             // :353 / :375, empty ticks elided
-                double d, l;
-                list_tick<FAST>(next, price, yp, d, l);
-                if (d == 0 || l == 0) {                                // :363-365 (initial is false here)
-                    pending = false;
-                } else {
-                    sd += d;
-                    sl += l;
-                    ++next;
-                    pending = --remaining > 0;
-                }
-            }
-        }
-        if (!trades) return (valid && t.d1 != t.d1) ? kDirBoth : kDirNone;     // (NaN price: t is all-NaN)
-        d_out = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;                 // :366-372 / :386-391
-        l_out = sl;
         return up ? kDir1 : kDir2;
     }
 };
@@ -776,12 +724,11 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
 // One pool: prices from LDS, closed form, trade record, dual scalar, netflow bins.
 template <class Ops, bool MAT, bool GBINS, bool FAST>
 __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a, const SweepLds& L,
-                                             const typename Ops::Raw& raw_in, int64_t i, bool valid, double& acc)
+                                             const typename Ops::Raw& raw_in, int64_t i, double& acc)
 {
     typename Ops::Raw raw = raw_in;
     ops.template resolve<GBINS, FAST>(raw, L.gtab);   // packed records: {tokens, fee-table index} -> tokens, fee
-    int2 tok = make_int2(0, 0);
-    if (valid) tok = ops.tokens(raw);
+    const int2 tok = ops.tokens(raw);
     Px px;                                            // v[r.cfmms[i].Ai]
     px.yg = raw.yg;
     if constexpr (GBINS) {
@@ -807,9 +754,7 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
     Trade t;
     double d, l;
     int dir;
-    if constexpr (Ops::kWaveCooperative) dir = ops.template solve_wave<FAST>(raw, valid, px, d, l, t);
-    else dir = ops.template solve_dir<FAST>(raw, px, d, l, t);
-    if (!valid) return;
+    dir = ops.template solve_dir<FAST>(raw, px, d, l, t);
     const double v1 = px.v1, v2 = px.v2;
     // One direction (the common case): the tendered token's bin gets −d, the received token's +l, the dual scalar
     // l·v_out − d·v_in -- the reference's expressions (src/router.jl:82, :99) with their zero terms dropped: same bits.
@@ -907,22 +852,13 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
                                           int64_t i, int64_t step, int64_t left, double& acc)
 {
     bool ok = left > 0;
-    if constexpr (Ops::kWaveCooperative) {
-        while (__any(ok)) {                          // the wavefront stays together
-            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, ok, acc);
-            if (ok) {
-                i += step;
-                ok = --left > 0;
-                if (ok) cur = ops.template load<GBINS>(i);
-            }
-        }
-    } else if constexpr (CFMM_PREFETCH != 0) {
+    if constexpr (CFMM_PREFETCH != 0) {
         while (ok) {
             const bool more = left > 1;
             // unconditional request (a conditional one makes the compiler wait for it at the join, before the
             // arithmetic): the last tile re-requests itself, a cache hit
             const typename Ops::Raw nxt = ops.template load<GBINS>(more ? i + step : i);
-            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
             cur = nxt;
             i += step;
             --left;
@@ -930,7 +866,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
         }
     } else {
         while (ok) {
-            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, true, acc);
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
             i += step;
             ok = --left > 0;
             if (ok) cur = ops.template load<GBINS>(i);
@@ -1049,12 +985,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
         sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
-        {   // the cooperative variant serves both shallow and deep segments here (no register cost:
-            // the fused kernel's footprint is set by the GeometricMean branch)
-            UniV3CoopOps ops;
-            ops.p = sg.pools.u;
-            sweep_body<UniV3CoopOps, MAT, BLOCK, GBINS>(ops, a, local, nblocks, bidx);
-        }
+        sweep_body<UniV3Ops, MAT, BLOCK, GBINS>(UniV3Ops{sg.pools.u}, a, local, nblocks, bidx);
         break;
     }
 }
@@ -1324,8 +1255,6 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     if (e != hipSuccess) return e;
     e = set_lds_attr<GeoMeanLogOps>(max_lds_bytes);
     if (e != hipSuccess) return e;
-    e = set_lds_attr<UniV3CoopOps>(max_lds_bytes);
-    if (e != hipSuccess) return e;
     return set_lds_attr<UniV3Ops>(max_lds_bytes);
 }
 
@@ -1359,10 +1288,7 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (!p.deep && !a.gflow) return launch_any(UniV3Ops{p}, a, c, mat, s);   // (large-market mode: cooperative variant only)
-    UniV3CoopOps ops;
-    ops.p = p;
-    return launch_any(ops, a, c, mat, s);
+    return launch_any(UniV3Ops{p}, a, c, mat, s);
 }
 
 hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1,

@@ -85,9 +85,7 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *   launch geometry   "block" (0 = auto | 512 | 1024 threads), "max_grid" (0 = auto), "bin_copies" (0 = auto, 1 = one
  *                     LDS netflow copy per block, 2 = one per wavefront), "fuse_segments" (default 1: all pool families
  *                     swept by one launch; 0: one launch per segment), "cost_geomean" / "cost_univ3" (cost of one
- *                     evaluation in tenths of a ProductTwoCoin one: how a fused launch divides its blocks; 10 / 10),
- *                     "univ3_coop" (-1 auto by walk-list length, 0 lane-per-pool walks only, 1 wavefront-cooperative
- *                     deep walks; per-segment launches only -- a fused launch always runs the cooperative variant)
+ *                     evaluation in tenths of a ProductTwoCoin one: how a fused launch divides its blocks; 10 / 10)
  *   data layout       "pack" (default 1: sweeps read an 8-byte {token pair, fee-table index} record instead of gamma +
  *                     Ai when a launch's distinct fees fit a 256-entry table), "compact_trades" (default 1: a
  *                     materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2,

@@ -142,10 +142,47 @@ def test_univ3_bit_exact_ragged_and_degenerate():
         assert rel_to_max(psi, psio) <= 1e-11
 
 
+def test_univ3_walk_decisions_at_tick_boundaries():
+    """The walk's drain decisions are taken on thresholds prepared at upload (UniV3Ops::solve_dir): `price <= T_j` must be
+    the reference's floating-point test `sqrt(k/price) − s_in >= δmax`, also when the price sits ON a tick boundary or a
+    few ulps beside it.  3000 two-token pools (γ = 1, so the walk's internal price is v₁/v₂ itself in one direction and
+    its reciprocal in the other) whose ladders put a boundary exactly at, and −3..+3 ulps around, the swept price."""
+    n, m = 2, 3000
+    rng = np.random.default_rng(7)
+    price = 1.37
+    nt = 8
+    off = nt * np.arange(m + 1, dtype=np.int64)
+    ticks, liq, cp = np.empty(m * nt), np.empty(m * nt), np.empty(m)
+    for i in range(m):
+        e = int(rng.integers(-3, 4))
+        hit = np.nextafter(price, np.inf) if e > 0 else (np.nextafter(price, 0) if e < 0 else price)
+        for _ in range(abs(e) - 1):
+            hit = np.nextafter(hit, np.inf if e > 0 else 0)
+        hit = hit if rng.random() < 0.5 else 1.0 / hit             # falling-price walks and rising-price walks
+        j = int(rng.integers(1, nt - 1))                           # which boundary carries the hit
+        lad = hit * 1.05 ** (j - np.arange(nt))                    # strictly descending, lad[j] == hit
+        ticks[off[i]:off[i + 1]] = lad
+        lq = 10.0 ** rng.uniform(2, 6, nt)
+        lq[rng.random(nt) < 0.15] = 0.0
+        liq[off[i]:off[i + 1]] = lq
+        k = int(rng.integers(0, nt))                               # current price somewhere in the ladder
+        cp[i] = lad[k] if rng.random() < 0.3 else lad[k] * rng.uniform(0.96, 1.0)
+    Ai = np.tile(np.array([[1, 2]]), (m, 1))
+    Ai[rng.random(m) < 0.5] = [2, 1]
+    b = cr.UniV3.batch(cp, off, ticks, liq, np.ones(m), Ai)
+    for v in ([price, 1.0], [1.0, price], [np.nextafter(price, 2), 1.0], [1.0, np.nextafter(price, 0)]):
+        v = np.array(v)
+        for fast in (1, 0):
+            D, L, psi, acc = device_sweep([b], n, v, fast_math=fast)
+            Do, Lo, psio, acco = oracle_sweep([b], n, v)
+            np.testing.assert_array_equal(D, Do)
+            np.testing.assert_array_equal(L, Lo)
+
+
 @pytest.mark.parametrize("t", [3, 64, 65, 200])
-def test_univ3_deep_walks_wave_cooperative(t):
-    """Ladders of t ticks with the external price far outside: walks cross up to ~t ticks, i.e. the
-    wavefront-cooperative phase (64 ticks per step) runs for 0, 1 and several batches.  Bit-exact."""
+def test_univ3_deep_walks(t):
+    """Ladders of t ticks with the external price far outside: walks cross up to ~t ticks -- the drained ticks through
+    the prefix sums of the records (threshold scan over 1 .. 25 lines), the last one tick by tick.  Bit-exact."""
     m, n = 3000, 8
     b = synth.univ3_pools(m, n, t, seed=t)
     for spread in (0.3, 8.0):                       # e^±8: every pool is drained in one direction
@@ -155,7 +192,7 @@ def test_univ3_deep_walks_wave_cooperative(t):
         np.testing.assert_array_equal(D, Do)
         np.testing.assert_array_equal(L, Lo)
         assert rel_to_max(psi, psio) <= 1e-11
-    # mixed launch (sweep_multi) exercises the same cooperative code next to lane-per-pool families
+    # mixed launch (sweep_multi): the same walk next to the other families
     D, L, psi, acc = device_sweep([synth.product_pools(5000, n, 1), b], n, v)
     Do, Lo, psio, acco = oracle_sweep([synth.product_pools(5000, n, 1), b], n, v)
     np.testing.assert_array_equal(D, Do)
