@@ -844,33 +844,18 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
 // the previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
 // 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
 // same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
-#ifndef CFMM_PREFETCH
-#define CFMM_PREFETCH 0   // 1: tile k+1's loads are issued before tile k is solved (A/B builds)
-#endif
+// (Requesting tile k+1 before tile k is solved was built and measured: +-0 warm, 2-3 % HBM-resident, at +8..16 VGPRs --
+// not kept, profiles/r03_ab_cold_geometry_prefetch_alternate.txt.)
 template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FAST>
 __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, const SweepLds& L, typename Ops::Raw cur,
                                           int64_t i, int64_t step, int64_t left, double& acc)
 {
     bool ok = left > 0;
-    if constexpr (CFMM_PREFETCH != 0) {
-        while (ok) {
-            const bool more = left > 1;
-            // unconditional request (a conditional one makes the compiler wait for it at the join, before the
-            // arithmetic): the last tile re-requests itself, a cache hit
-            const typename Ops::Raw nxt = ops.template load<GBINS>(more ? i + step : i);
-            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
-            cur = nxt;
-            i += step;
-            --left;
-            ok = more;
-        }
-    } else {
-        while (ok) {
-            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
-            i += step;
-            ok = --left > 0;
-            if (ok) cur = ops.template load<GBINS>(i);
-        }
+    while (ok) {
+        process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
+        i += step;
+        ok = --left > 0;
+        if (ok) cur = ops.template load<GBINS>(i);
     }
 }
 

@@ -143,12 +143,15 @@ class Router:
     # r.Δs / r.Λs: [m, 2] arrays in router order (rows are the reference's per-pool vectors)
     def _fetch(self):
         if self._trades_stale:
-            D, Lm = self._backend.trades()
             if self._order is not None:
+                D, Lm = self._backend.trades()
                 self._Δs[self._order] = D
                 self._Λs[self._order] = Lm
-            else:
-                self._Δs, self._Λs = D, Lm
+            else:           # find_arb! overwrites r.Δs / r.Λs in place (src/router.jl:40): the router's own arrays are filled
+                if isinstance(self._backend, DeviceBackend):
+                    self._backend.trades(out=(self._Δs, self._Λs))
+                else:                   # test-injected backends
+                    self._Δs, self._Λs = self._backend.trades()
             self._trades_stale = False
 
     @property
