@@ -71,6 +71,8 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     int sweeps = 0, rc_inner = CFMM_OK;
     double sweep_s = 0.0;
     const auto t_begin = std::chrono::steady_clock::now();
+    c->sweep_count = 0;        // tile directions (option "alternate") are a function of this call alone: evaluation k
+    for (cfmm_ctx* s : c->shards) s->sweep_count = 0;   // walks in direction k & 1, the final find_arb! forwards
     bool armed = can_arm(c);   // (switched off for the rest of the call after a lost hand-over)
     struct ArmGuard {   // whatever path leaves this function: no launch stays behind waiting for a price vector
         cfmm_ctx* c;

@@ -473,7 +473,12 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
-    if (materialize) c->trade_v.assign(v, v + c->n);   // the prices the device trades belong to (update_reserves!)
+    if (materialize) {
+        c->trade_v.assign(v, v + c->n);   // the prices the device trades belong to (update_reserves!)
+        // find_arb!(r, v) is a function of v alone (test/arb.jl:16 compares its netflows exactly): a materialising host call
+        // always walks forwards, whatever ran before; the alternation (option "alternate") restarts behind it.
+        c->sweep_count = 0;
+    }
     double* h_out = c->h_stage + c->n;
     const bool zero_copy = c->opt_zero_copy != 0 && c->d_stage != nullptr;
     // v: small vectors are read by every block straight from the mapped pinned buffer (the PCIe

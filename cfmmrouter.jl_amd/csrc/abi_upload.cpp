@@ -298,6 +298,7 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
         work(0, nrec / nthr);
         for (auto& th : pool) th.join();
     }
+    thr.resize(ticks.size() + 4, 0.0);   // the scan reads four thresholds at a time
     s.has_walk = longest > 0 ? 1 : 0;
     s.fast_ok = fast ? 1 : 0;
     int rc;

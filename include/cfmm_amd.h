@@ -97,10 +97,12 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     price or a fee reuse a reciprocal refined once per token / fee tier: same bits, ~half the
  *                     instructions; 0: the compiler's sequences everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
  *                     with pow in the reference's operation order instead of the default log-space form; both are within
- *                     1e-12 of the reference), "alternate" (default 1: consecutive sweeps walk every lane's tiles in
+ *                     1e-12 of the reference), "alternate" (default 1: consecutive evaluations walk every lane's tiles in
  *                     alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's
- *                     L2 -- two sweeps at the same v then agree to summation-order rounding (trades: bit for bit), every
- *                     second one bit for bit; 0: always forwards, every sweep bit-identical)
+ *                     L2 -- two fused evaluations at the same v then agree to summation-order rounding, every second one
+ *                     bit for bit.  cfmm_find_arb and the final sweep of cfmm_route always walk forwards: find_arb!(r, v)
+ *                     is a function of v alone, and cfmm_route restarts the alternation, so a route is a function of its
+ *                     arguments alone; 0: always forwards, every sweep bit-identical)
  *   host boundary     "zero_copy" (default 1: host-pointer calls read v through mapped pinned memory), "host_flag"
  *                     (default 1: such a call ends when {psi, acc} have arrived in pinned host memory as self-validating
  *                     8-byte granules, which the library polls, instead of on the stream's completion signal),

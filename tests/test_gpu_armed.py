@@ -47,7 +47,7 @@ def test_armed_route_is_bit_identical_to_the_unarmed_loop(name, n, batches):
     np.testing.assert_array_equal(a[4], b[4])         # Λ
     np.testing.assert_array_equal(a[6], a[3])         # a later plain find_arb! at v* reproduces the trades
     np.testing.assert_array_equal(a[7], a[4])
-    assert np.max(np.abs(a[5] - a[1])) <= 1e-13 * np.max(np.abs(a[1]))
+    np.testing.assert_array_equal(a[5], a[1])         # ... and Ψ(v*): find_arb!(r, v) is a function of v alone
 
 
 def test_armed_route_basket_liquidation_many_evaluations():
@@ -74,6 +74,8 @@ def test_armed_route_repeated_and_interleaved_with_other_calls():
             v, psi, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=np.ones(n))
             psi_e, acc_e = be.eval(v)                      # ordinary launches right behind a cancelled armed one
             assert np.max(np.abs(psi_e - psi)) <= 1e-13 * np.max(np.abs(psi))
+            psi_m, acc_m = be.find_arb(v)                  # find_arb!(r, r.v) after route!: the route's own final sweep
+            np.testing.assert_array_equal(psi_m, psi)
             if first is None:
                 first = (v.copy(), info["evaluations"])
             else:

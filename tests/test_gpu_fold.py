@@ -122,25 +122,30 @@ def test_determinism_claim_is_conditional_on_private_bin_copies():
 
 
 def test_alternating_tile_direction_is_rounding_only():
-    """Option "alternate" (default 1): consecutive sweeps walk every lane's tiles in alternating directions so that a
-    sweep starts on the pool data the previous one left in the XCD's L2.  Same direction => same bits; opposite
-    direction => summation-order rounding; trades are bit-identical either way; alternate = 0 => every sweep equal."""
+    """Option "alternate" (default 1): consecutive evaluations walk every lane's tiles in alternating directions so that a
+    sweep starts on the pool data the previous one left in the XCD's L2.  find_arb!(r, v) itself always walks forwards
+    (a function of v alone, test/arb.jl:16); fused evaluations: same direction => same bits, opposite direction =>
+    summation-order rounding; alternate = 0 => every sweep equal."""
     n = 256
     batches = [synth.product_pools(400_000, n, seed=101), synth.geomean_pools(300_000, n, seed=102)]
     v = synth.sweep_prices(n, seed=103)
     be = cr.DeviceBackend(n, batches)
     try:
         runs = []
-        for _ in range(4):
+        for k in range(4):
+            for _ in range(k):
+                be.eval(v * (1.0 + 0.01 * k))              # whatever ran before
             psi, acc = be.find_arb(v)
             runs.append((psi, acc, be.trades()))
-        np.testing.assert_array_equal(runs[0][0], runs[2][0])
-        np.testing.assert_array_equal(runs[1][0], runs[3][0])
-        assert runs[0][1] == runs[2][1] and runs[1][1] == runs[3][1]
-        assert rel_to_max(runs[1][0], runs[0][0]) <= 1e-14
         for k in (1, 2, 3):
+            np.testing.assert_array_equal(runs[k][0], runs[0][0])          # Ψ
+            assert runs[k][1] == runs[0][1]
             np.testing.assert_array_equal(runs[k][2][0], runs[0][2][0])    # Δ
             np.testing.assert_array_equal(runs[k][2][1], runs[0][2][1])    # Λ
+        back, fwd = be.eval(v), be.eval(v)                 # behind a find_arb!: backwards, then forwards again
+        np.testing.assert_array_equal(fwd[0], runs[0][0])
+        assert fwd[1] == runs[0][1]
+        assert rel_to_max(back[0], runs[0][0]) <= 1e-14
         be.ctx.set_option("alternate", 0)
         a, b = be.eval(v), be.eval(v)
         np.testing.assert_array_equal(a[0], b[0])
