@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(src, "benchfull_*.log")):
     if lines:
         w = os.path.basename(f)[10:-4]
         json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{rnd}_bench_{w}.json"), "w"), indent=1)
-for w in {os.path.basename(d).split("_")[1] for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)}:
+for w in {os.path.basename(d)[4:].rsplit("_", 2)[0] for d in glob.glob(os.path.join(src, "pmc_*_SIZE")) if os.path.isdir(d)}:
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(src, f"pmc_{w}_{c}", "**", "*counter_collection.csv"), recursive=True)
