@@ -757,11 +757,14 @@ int armed_eval(cfmm_ctx* c, const double* v, bool* lost_out)
         bool lost = false;
         const int rw = armed_wait(child, want[(size_t)d], lost);
         any_lost = any_lost || lost;
+        running[(size_t)d] = (rw == CFMM_OK && !lost) ? 2 : 1;   // 2: this shard delivered the evaluation
         const int r = rw != CFMM_OK ? rw : rcs[(size_t)d];
         if (r != CFMM_OK && first_err == CFMM_OK) { first_err = r; err_shard = d; }
     }
     if (any_lost) {
         armed_cancel(c);
+        for (int d = 0; d < nd; ++d)   // shards that did deliver repeat the evaluation too: it takes the same tile direction
+            if (running[(size_t)d] == 2) --c->shards[(size_t)d]->sweep_count;
         if (lost_out) *lost_out = true;
         return multi_host_sweep(c, v, false);
     }
