@@ -611,6 +611,13 @@ __device__ __forceinline__ void store_pair(double2* dst, double x, double y)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(val) : "memory");
 }
 
+// Partial rows are written through as well: no dirty line is left for the end-of-kernel release in front of the fold
+// launch (A/B: -0.3..-0.45 us per step on single-family launches, +-0.1 on config3; profiles/r03_ab_row_write_through.txt).
+__device__ __forceinline__ void store_row(double* dst, double x)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(dst), "v"(x) : "memory");
+}
+
 // One block's share of a segment: tiles bid, bid+nblocks, ... of the segment's pools; its
 // partial row goes to partials[row].
 // GBINS = true is the large-market mode (n_tokens > kMaxLdsTokens, v and the bins no longer fit
@@ -901,12 +908,12 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     for (int j = tid; j < n_cols; j += BLOCK) {
         double s = L.bins[j];
         for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
-        row[j] = s;
+        store_row(row + j, s);
     }
     if (tid == 0) {
         double s = L.wsum[0];
         for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
-        row[n_cols] = s;
+        store_row(row + n_cols, s);
     }
 }
 
