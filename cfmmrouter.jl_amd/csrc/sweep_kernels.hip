@@ -567,12 +567,25 @@ struct UniV3Ops {
         const int count = up ? r.walk.y : r.walk.w;
         int j = 0;
         const bool jump = cur != kCurPartial && count > 0;
+        TickRec rec;
+        double thr_j = 0.0;                                                // T[j] of the tick the scan stopped at
+        bool have = false;
         if (jump) {
+            // ticks 0..j−1 drain.  Four thresholds per round trip (the dependent chain of a walking pool is
+            // walk span -> thresholds -> one record); every list ends in a 0 and the array is padded, so reading past
+            // a short list is harmless and the first failing test ends the scan exactly like one-by-one.
             const double* T = p.thr + begin;
-            while (j < count && price <= T[j]) ++j;                        // ticks 0..j−1 drain
-            const double2 before = p.ticks[begin + j].psum;               // (j == count: the list's closing record)
-            sd = before.x;
-            sl = before.y;
+            for (;;) {
+                const double t0 = T[j], t1 = T[j + 1], t2 = T[j + 2], t3 = T[j + 3];
+                const int adv = !(price <= t0) ? 0 : !(price <= t1) ? 1 : !(price <= t2) ? 2 : !(price <= t3) ? 3 : 4;
+                thr_j = adv == 0 ? t0 : adv == 1 ? t1 : adv == 2 ? t2 : t3;
+                j += adv;
+                if (adv < 4) break;
+            }
+            rec = p.ticks[begin + j];                                      // (j == count: the list's closing record)
+            have = true;
+            sd = rec.psum.x;
+            sl = rec.psum.y;
         } else if (cur == kCurDrained) {
             const double2 R = p.curR[r.i];                                 // no list in this direction: the current tick alone
             sd = up ? r.cb.y : r.cc;
@@ -580,11 +593,16 @@ struct UniV3Ops {
         }
         for (; j < count; ++j) {                                           // :353 / :375, empty ticks elided
             double dj, lj;
-            list_tick<FAST>(p.ticks[begin + j], price, yp, dj, lj);
+            if (!have) {
+                rec = p.ticks[begin + j];
+                if (jump) thr_j = p.thr[begin + j];
+            }
+            have = false;
+            list_tick<FAST>(rec, price, yp, dj, lj);
             if (dj == 0 || lj == 0) break;                                 // :363-365 (initial is false here)
             sd += dj;
             sl += lj;
-            if (jump && price > p.thr[begin + j] * (1.0 + 0x1p-40)) break;   // the next tick cannot be entered (see above)
+            if (jump && price > thr_j * (1.0 + 0x1p-40)) break;            // the next tick cannot be entered (see above)
         }
         d = FAST ? div_by_signed_zero(sd, g, yg) : sd / g;                 // :366-372 / :386-391
         l = sl;
