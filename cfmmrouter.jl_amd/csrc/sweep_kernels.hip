@@ -97,6 +97,38 @@ __device__ __forceinline__ double fast_sqrt(double x)
     d = __builtin_fma(-s, s, x);
     return __builtin_fma(d, h, s);
 }
+// exp(x) for |x| < 700 (no overflow / underflow handling: inside the window of the fast arithmetic the argument is the
+// logarithm of a reserve, |x| <= ~312), < 1 ulp like the device library's: x = k ln2 + r, |r| <= ln2/2,
+// exp(r) = 1 + r + r^2 g(r) with g the degree-9 Chebyshev interpolant of (e^r - 1 - r)/r^2 (approximation error 1.6e-17,
+// scripts/fit_exp.py), result ldexp(., k).  19 instructions against the library's 38: that one handles the whole
+// double range (two compares, four selects) and the compiler expands its Horner steps into v_mov + v_fmac pairs; here
+// each step is ONE v_fma with the coefficient in scalar registers.  NaN in, NaN out.
+__device__ __forceinline__ double fma_sc(double x, double acc, double c)   // x * acc + c, c from SGPRs
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(acc), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double fast_exp(double x)
+{
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(-k, 0x1.62e42fefa39efp-1, x);
+    r = __builtin_fma(-k, 0x1.abc9e3b39803fp-56, r);
+    double p = 0x1.af39091a8441ap-26;
+    p = fma_sc(r, p, 0x1.2891d2ecb3ed9p-22);
+    p = fma_sc(r, p, 0x1.71de0d863c737p-19);
+    p = fma_sc(r, p, 0x1.a019b8cbe6585p-16);
+    p = fma_sc(r, p, 0x1.a01a01a7ce75dp-13);
+    p = fma_sc(r, p, 0x1.6c16c1789caa1p-10);
+    p = fma_sc(r, p, 0x1.11111111109a6p-7);
+    p = fma_sc(r, p, 0x1.5555555553d38p-5);
+    p = fma_sc(r, p, 0x1.5555555555556p-3);
+    p = fma_sc(r, p, 0x1.0000000000001p-1);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
 // |x| in [2^-kFastExp, 2^kFastExp] (false for NaN, infinities, zero, denormals)
 __device__ __forceinline__ bool in_fast_window(double x)
 {
@@ -379,7 +411,7 @@ struct GeoMeanLogOps {
         const double A = dir1 ? (r.Q.x + px.dlv) : (r.Q.y - eta * px.dlv);
         double X, Y;
         if constexpr (FAST) {   // same correctly rounded quotients for operands inside the window (checked at upload / staging)
-            X = exp(fast_div(A, eta + 1.0));
+            X = fast_exp(fast_div(A, eta + 1.0));
             Y = fast_div((X * ra) * dd, n);
             d = div_by(max0(X - rb), g, px.yg);
         } else {

@@ -95,7 +95,9 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     upload, prices by every block as it stages them -- divisions and square roots run the compiler's
  *                     own correctly-rounded instruction sequences WITHOUT their range scaffolding, and divisions by a
  *                     price or a fee reuse a reciprocal refined once per token / fee tier: same bits, ~half the
- *                     instructions; 0: the compiler's sequences everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
+ *                     instructions; the log-space GeometricMean form -- within 1e-12 of the reference either way --
+ *                     also evaluates its exponential with an own < 1 ulp polynomial instead of the device library's;
+ *                     0: the compiler's sequences and the library's exp everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
  *                     with pow in the reference's operation order instead of the default log-space form; both are within
  *                     1e-12 of the reference), "alternate" (default 1: consecutive evaluations walk every lane's tiles in
  *                     alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's

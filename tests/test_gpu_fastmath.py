@@ -29,3 +29,8 @@ def test_fast_division_and_sqrt_match_the_ieee_sequences(tmp_path):
     f = dict(kv.split("=") for kv in line.split()[1:])
     assert int(f["pairs"]) == 4096 * 256 * 1024
     assert f["div_mismatch"] == "0" and f["sqrt_mismatch"] == "0" and f["zero_mismatch"] == "0"
+    # fast_exp (log-space GeometricMean form): within an ulp of the device library's exp almost everywhere, never more
+    # than 2 apart, and < 1 ulp from the long-double exponential on the sample the host re-computes
+    assert int(f["exp_max_ulp_vs_lib"]) <= 2
+    assert int(f["exp_over_1ulp_vs_lib"]) <= int(f["pairs"]) // 1000
+    assert float(f["exp_max_err_ulp_vs_expl"]) < 1.0

@@ -281,12 +281,20 @@ def test_fast_math_is_bit_identical_and_falls_back_outside_its_window(scale_exp)
             res[fast] = (psi, acc) + be.trades()
         finally:
             be.close()
-    np.testing.assert_array_equal(res[1][2], res[0][2])
-    np.testing.assert_array_equal(res[1][3], res[0][3])
-    np.testing.assert_array_equal(res[1][0], res[0][0])
-    assert res[1][1] == res[0][1]
+    g0, g1 = 60_000, 90_000     # rows [g0, g1) are GeometricMeanTwoCoin pools
+    for k in (2, 3):            # ProductTwoCoin and UniV3 rows: the same bits
+        np.testing.assert_array_equal(res[1][k][:g0], res[0][k][:g0])
+        np.testing.assert_array_equal(res[1][k][g1:], res[0][k][g1:])
+    # GeometricMean (log-space form, within 1e-12 of the reference either way): the fast arithmetic evaluates the one
+    # exponential with its own < 1 ulp polynomial instead of the device library's, so trades agree to a few ulp
+    scale = np.maximum(batches[1].R.max(axis=1), 1.0)[:, None]
+    for k in (2, 3):
+        assert np.max(np.abs(res[1][k][g0:g1] - res[0][k][g0:g1]) / scale) <= 1e-14
+    assert rel_to_max(res[1][0], res[0][0]) <= 1e-13 and abs(res[1][1] - res[0][1]) <= 1e-13 * abs(res[0][1])
+    if abs(scale_exp) > 150:    # outside the window both runs take the compiler's sequences and the library's exp
+        for a, b in zip(res[1], res[0]):
+            np.testing.assert_array_equal(a, b)
     Do, Lo, psi_o, _ = oracle_sweep(batches, n, v, nthreads=8)
-    g0, g1 = 60_000, 90_000     # ProductTwoCoin and UniV3 rows: bit-exact against the CPU restatement
     np.testing.assert_array_equal(res[1][2][:g0], Do[:g0])
     np.testing.assert_array_equal(res[1][3][:g0], Lo[:g0])
     np.testing.assert_array_equal(res[1][2][g1:], Do[g1:])
