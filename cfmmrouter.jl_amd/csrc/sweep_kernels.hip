@@ -612,8 +612,9 @@ struct UniV3Ops {
                 const int adv = !(price <= t0) ? 0 : !(price <= t1) ? 1 : !(price <= t2) ? 2 : !(price <= t3) ? 3 : 4;
                 thr_j = adv == 0 ? t0 : adv == 1 ? t1 : adv == 2 ? t2 : t3;
                 j += adv;
-                if (adv < 4) break;
+                if (adv < 4 || j >= count) break;
             }
+            j = j < count ? j : count;   // (prices <= 0 from a caller's device vector pass every test, the closing 0 included)
             rec = p.ticks[begin + j];                                      // (j == count: the list's closing record)
             have = true;
             sd = rec.psum.x;

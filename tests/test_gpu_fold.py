@@ -328,3 +328,38 @@ def test_fast_math_price_window_is_checked_by_every_block(vscale):
     Do, Lo, _, _ = oracle_sweep(batches, n, v, nthreads=8)
     np.testing.assert_array_equal(res[1][1], Do)
     np.testing.assert_array_equal(res[1][2], Lo)
+
+
+@pytest.mark.parametrize("bad", [-1.0, 0.0, float("nan"), float("inf")])
+def test_device_pointer_sweep_with_invalid_prices_stays_in_bounds(bad):
+    """cfmm_sweep_dev never sees its price vector on the host, so nothing validates it (the host-pointer calls do,
+    src/cfmms.jl:129).  Garbage in, garbage out -- but every walk stays inside its list (the threshold scan of a UniV3
+    pool is bounded by the list's length, not only by its closing record), nothing faults, and the next sweep at valid
+    prices is exact again."""
+    import torch
+    n = 32
+    batches = [synth.product_pools(30_000, n, seed=701), synth.geomean_pools(20_000, n, seed=702),
+               synth.univ3_ragged_pools(40_000, n, seed=703)]
+    v = synth.sweep_prices(n, seed=704)
+    vb = v.copy()
+    vb[::5] = bad
+    be = cr.DeviceBackend(n, batches)
+    try:
+        ot = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        for mat in (True, False):
+            be.ctx.sweep_dev(torch.from_numpy(vb).cuda().data_ptr(), ot.data_ptr(), mat)
+            torch.cuda.synchronize()
+        vt = torch.from_numpy(v).cuda()
+        be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
+        torch.cuda.synchronize()
+        D, L = be.trades()
+        Do, Lo, psi_o, acc_o = oracle_sweep(batches, n, v, nthreads=8)
+        g0, g1 = 30_000, 50_000
+        np.testing.assert_array_equal(D[:g0], Do[:g0])
+        np.testing.assert_array_equal(D[g1:], Do[g1:])
+        np.testing.assert_array_equal(L[g1:], Lo[g1:])
+        out = ot.cpu().numpy()
+        assert rel_to_max(out[:n], psi_o) <= 1e-12
+    finally:
+        be.close()
+
