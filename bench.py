@@ -50,6 +50,64 @@ ALG_BYTES = {KIND_PRODUCT: 32 + 32, KIND_GEOMEAN: 48 + 32}
 ALG_BYTES_FUSED = {KIND_PRODUCT: 32, KIND_GEOMEAN: 48}
 
 
+def live_traffic(workload, fused, opts):
+    """roofline.traffic measured NOW: HBM bytes per sweep launch from two bounded rocprofv3 PMC passes of this very command
+    (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs with --kernel-trace only, MI355X_MICROARCH.md §HBM: both
+    in KiB, FETCH_SIZE doubled on gfx950).  Returns (bytes, detail) or (None, reason).  The child runs are this script with
+    --no-cpu --no-cold --no-live-traffic; each is bounded, and on a time-out exactly the process group started here is
+    killed."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if os.environ.get("CFMM_BENCH_CHILD") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "already inside a profiled run"
+    tmp = tempfile.mkdtemp(prefix="cfmm_pmc_", dir="/tmp")
+    env = dict(os.environ, CFMM_BENCH_CHILD="1", TMPDIR="/tmp")
+    counters = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, c), "-o", "w", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "3", "--no-cpu", "--no-cold",
+                   "--no-live-traffic", "--workload", workload] + (["--fused"] if fused else [])
+            for o in opts:
+                cmd += ["--opt", o]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)     # the session started above, nothing else
+                p.wait()
+                return None, f"rocprofv3 --pmc {c} timed out"
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, c, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == c and "cfmm::sweep" in row["Kernel_Name"]:
+                        acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not acc:
+                return None, f"rocprofv3 --pmc {c}: no counter rows (exit code {p.returncode})"
+            counters[c] = {k: sum(v) / len(v) for k, v in acc.items()}
+        tag = ("<false,", " false,") if fused else ("<true,", " true,")
+        total, detail = 0.0, {}
+        for k in sorted(set(counters["FETCH_SIZE"]) | set(counters["WRITE_SIZE"])):
+            if not any(t in k for t in tag):
+                continue
+            f, w = counters["FETCH_SIZE"].get(k, 0.0), counters["WRITE_SIZE"].get(k, 0.0)
+            detail[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+            total += detail[k]["hbm_bytes_per_launch"]
+        return (total, detail) if detail else (None, "no sweep kernel of this variant in the counter rows")
+    except Exception as e:      # a profiler problem must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def alg_bytes(batches, materialize=True, v=None):
     """SURVEY §8d bytes of one launch.  UniV3: 32 B header + 16 B per tick (+ 32 B of trades); multi-tick ladders
     (`v` given): per tick VISITED by the walk at these prices, not per tick stored."""
@@ -566,6 +624,9 @@ def main():
     ap.add_argument("--fused", action="store_true", help="time the fused evaluation (no Δ/Λ write-back)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-cold pass")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 PMC passes of this command (two bounded child runs); "
+                         "use the committed profiles/traffic.json")
     ap.add_argument("--rccl", action="store_true", help="force the RCCL all-reduce instead of the one-shot peer gather")
     ap.add_argument("--cold-only", action="store_true",
                     help="the timed region rotates over > 300 MB of market copies (pool state from HBM, not the Infinity "
@@ -688,14 +749,23 @@ def main():
     value = world * sb.m_rank * args.steps / elapsed
     bytes_per_launch = alg_bytes(sb.batches, materialize, sb.v)
     achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_detail = None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
+    if world == 1 and not use_dist and not args.no_cpu and not args.no_live_traffic:
+        traffic, traffic_detail = live_traffic(args.workload, args.fused, args.opt)
+        if traffic is not None:
+            traffic_src = ("measured in this run: HBM bytes per sweep launch from two rocprofv3 PMC passes of this command "
+                           "(--pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child runs with --kernel-trace only; KiB, "
+                           "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)")
+        else:
+            traffic_src = f"live PMC pass unavailable ({traffic_detail}); "
+            traffic_detail = None
+    if traffic is None and os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get(args.workload + ("_fused" if args.fused else ""))
-            traffic_src = ("HBM bytes per launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE, WRITE_SIZE "
-                           "in separate runs, gfx950 corrections of MI355X_MICROARCH.md; profiles/traffic.json) -- PMC counters "
-                           "cannot be read from inside this process")
+            traffic_src = (traffic_src or "") + (
+                "HBM bytes per launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE, WRITE_SIZE "
+                "in separate runs, gfx950 corrections of MI355X_MICROARCH.md; profiles/traffic.json)")
         except Exception:
             traffic = None
 
@@ -724,7 +794,7 @@ def main():
               "achieved": moved / (hbm["kernel_ms"] * 1e-3) / 1e9 if hbm["kernel_ms"] > 0 else 0.0}
     layout["frac"] = layout["achieved"] / HBM_PEAK_GBS
     roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                 "kernel": "cfmm::sweep_multi / cfmm::sweep_kernel (the sweep launch of one step)",
                 "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": hbm["kernel_ms"], "residency": resid,
                 "layout": layout, "warm": warm, "cold": cold,
