@@ -80,7 +80,7 @@ def live_traffic(workload, fused, opts):
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                p.wait(timeout=150)
+                p.wait(timeout=90)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)     # the session started above, nothing else
                 p.wait()
