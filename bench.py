@@ -663,6 +663,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit(f"[rank {rank}/{world}] bench.py needs an MI355X; there is no CPU fallback for the product path")
+    # CFMM_BENCH_SHARE_GPU=1 (rehearsal of the N > 1 orchestration on a 1-GPU box: shard indexing, global-market parity,
+    # max over ranks, the strong-scaling leg): the ranks share the visible GPUs round-robin and rendezvous over gloo --
+    # RCCL does not share a device between ranks.  The line it prints is NOT a measurement (`config.rehearsal`).
+    share = os.environ.get("CFMM_BENCH_SHARE_GPU") == "1"
+    if share and torch.cuda.device_count() > 0:
+        local_rank %= torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"[rank {rank}/{world}] local rank {local_rank} has no GPU: {torch.cuda.device_count()} visible "
                          f"(one rank per GPU; RCCL does not share a device between ranks)")
@@ -673,7 +679,10 @@ def main():
         # a healthy peer exchange takes microseconds and the bench's ranks run in lockstep: bound a broken one (the
         # start-up check then falls back to RCCL on all ranks) by seconds, not by the library's 30 s default
         os.environ.setdefault("CFMM_AMD_PEER_TIMEOUT_S", "5")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sb = ShardBench(args, args.workload, args.scaling, rank, world, local_rank, use_dist)
     n, be, materialize = sb.n, sb.be, sb.materialize
@@ -817,7 +826,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sb.desc}", "pools_per_gpu": sb.m_rank, "pools_total": world * sb.m_rank,
                    "n_tokens": n, "variant": "materialising" if materialize else "fused", "segments": be.ctx.segments(),
-                   "sharding": sb.sharding_text()},
+                   "sharding": sb.sharding_text(), **({"rehearsal": "ranks share a GPU over gloo: not a measurement"} if share else {})},
         "roofline": roofline,
         "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "fast_math", "armed",
                                                                "stop_in_noise", "host_flag", "zero_copy")},

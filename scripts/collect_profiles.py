@@ -21,7 +21,7 @@ for f in glob.glob(os.path.join(src, "tune_*.txt")):
 if os.path.exists(os.path.join(src, "traffic.json")):
     shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, "traffic.json"))
 for name in ("floor.txt", "dist_world1.json", "bench_torchrun_world1_peer.json", "bench_torchrun_world1_rccl.json",
-             "bench_single_process_3shards.json", "pytest_gpu.log", "smoke.log"):
+             "bench_single_process_3shards.json", "bench_rehearsal_world2.json", "pytest_gpu.log", "smoke.log"):
     if os.path.exists(os.path.join(src, name)):
         out = {"floor.txt": "launch_floor.txt"}.get(name, name)
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{out}"))

@@ -97,3 +97,33 @@ def test_sharded_route_across_processes_sharing_one_gpu(world):
     assert out["ranks_bit_identical"] and out["pools_total"] == 460_000
     assert out["fixed_v_rel_diff"] <= 1e-13
     assert out["route_native_rel_diff"] <= 1e-6 and out["route_scipy_rel_diff"] <= 1e-6 and out["evaluations"] >= 5
+
+
+def test_bench_rehearsal_world2_on_one_gpu():
+    """The N > 1 orchestration of bench.py at world = 2 on the ONE GPU of this box (CFMM_BENCH_SHARE_GPU=1: both ranks on
+    device 0, rendezvous over gloo because RCCL does not share a device): shard indexing, the in-library peer exchange
+    between two PROCESSES, the start-up collective check, global-market oracle parity on rank 0, the sharded route! and
+    the strong-scaling leg (config 4 divided among the ranks).  Timings of such a run mean nothing (`config.rehearsal`);
+    what is asserted is that the line exists and that its parity figures are those of an N = 1 run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--opt", "armed=0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, CFMM_BENCH_SHARE_GPU="1"))
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line["config"]
+    assert line["config"]["pools_total"] == 2 * line["config"]["pools_per_gpu"]
+    assert line["collective_check_rel_err"] <= 1e-12
+    par = line["parity"]
+    assert par["netflow_rel_err_at_fixed_v"] <= 1e-12 and par["dual_rel_err"] <= 1e-12
+    assert par["route_sharded_netflow_rel_err"] <= 1e-6
+    rs = line["route_sharded"]
+    assert "error" not in rs and rs["ranks_agree_on_v"] and rs["pools_total"] == line["config"]["pools_total"]
+    ss = line["strong_scaling"]
+    assert ss["pools_total"] == 4_000_000 and ss["pools_per_gpu"] == 2_000_000 and ss["collective_check_rel_err"] <= 1e-12
+    assert line["cpu_baseline"]["value"] > 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(line, open(os.path.join(ROOT, "gpurun_out", "bench_rehearsal_world2.json"), "w"), indent=1)
+
