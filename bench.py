@@ -584,6 +584,13 @@ def sharded_route(sb, local_rank):
         obj = objective_for(sb.name, sb.n)
         v0 = np.ones(sb.n) if isinstance(obj, cr.LinearNonnegative) else None
         sr = crd.ShardedRouter(obj, sb.batches, sb.n, device=local_rank, already_sharded=True)
+        ctx = getattr(sr._backend, "ctx", None) or getattr(getattr(sr._backend, "local", None), "ctx", None)
+        if ctx is not None:
+            for kv in sb.args.opt:
+                k, val = kv.split("=")
+                ctx.set_option(k, int(val))
+            if os.environ.get("CFMM_BENCH_SHARE_GPU") == "1":
+                ctx.set_option("armed", 0)   # ranks that share a GPU: a waiting launch of one rank holds the CUs another rank's sweep of the SAME evaluation needs
         cr.route_(sr, v=v0, solver="native")   # warm
     except Exception as e:
         err = repr(e)[:300]
