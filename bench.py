@@ -202,6 +202,8 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
 
     ps = oracle_poolset(batches, n)
     threads = orc.lib().oracle_max_threads()
+    if "TORCHELASTIC_RUN_ID" in os.environ:   # torchrun exports OMP_NUM_THREADS=1; rank 0 is the only rank doing host work here
+        threads = max(threads, len(os.sched_getaffinity(0)))
     m = ps.m
     reps, t_tot = 0, 0.0
     ps.sweep(v, threads)  # warm caches / thread pool
