@@ -9,7 +9,8 @@ from .cfmms import (CFMM, BoundedProduct, GeometricMeanTwoCoin, PoolBatch, Produ
                     grad_phi_, phi, zerotrade, ϕ, ϕ_grad_)
 from .objectives import (BasketLiquidation, LinearNonnegative, Objective, Swap, f, grad_, lower_limit,
                          upper_limit)
-from .router import DeviceBackend, Router, find_arb_ as _find_arb_router, netflows, netflows_, route_, update_reserves_
+from .router import (DeviceBackend, Router, dual_jacobian, find_arb_ as _find_arb_router, netflows, netflows_, polish_, route_,
+                     update_reserves_)
 
 
 def find_arb_(*args, **kw):
@@ -24,4 +25,5 @@ __all__ = [
     "update_reserves_", "Objective", "LinearNonnegative", "BasketLiquidation", "Swap", "f", "grad_",
     "lower_limit", "upper_limit", "Router", "route_", "netflows_", "netflows", "ArgumentError",
     "CFMMDeviceError", "Context", "DeviceBackend", "build", "lib", "zerotrade", "ϕ", "ϕ_grad_", "phi", "grad_phi_",
+    "polish_", "dual_jacobian",
 ]

@@ -285,6 +285,87 @@ def _route_native(r: Router, v, m, factr, pgtol, maxfun, maxiter):
     return None
 
 
+def _dual_gradient(r: Router, x):
+    """G(ν) = ∇f(obj, ν) + Ψ(ν) of g! (src/router.jl:89-102) at ν = x: one fused sweep."""
+    psi, acc = r._backend.eval(x)
+    r.n_sweeps += 1
+    G = np.zeros(x.size)
+    _obj.grad_(G, r.objective, x)
+    return G + psi, psi, acc
+
+
+def dual_jacobian(r: Router, v=None, rel_step=1e-7):
+    """Forward-difference Jacobian of the dual gradient G(ν) = ∇f(obj, ν) + Ψ(ν) (src/router.jl:89-102) at ν = v
+    (default r.v): column j = (G(ν + hⱼeⱼ) − G(ν)) / hⱼ with hⱼ = rel_step·νⱼ -- n_tokens + 1 fused sweeps.  It is the
+    Hessian of the dual where that exists (the dual is C¹ and piecewise C²: pools enter and leave their no-trade band).
+    `polish_` uses it as the matrix of a chord-Newton iteration, where only its rough accuracy matters."""
+    x = np.array(r.v if v is None else v, dtype=np.float64)
+    G0, _, _ = _dual_gradient(r, x)
+    J = np.empty((x.size, x.size))
+    for j in range(x.size):
+        xj = x.copy()
+        xj[j] = x[j] * (1.0 + rel_step)
+        J[:, j] = (_dual_gradient(r, xj)[0] - G0) / (xj[j] - x[j])
+    return J
+
+
+def polish_(r: Router, iters=8, jacobian=None, rel_step=1e-7):
+    """Tighten a route!'s result beyond what L-BFGS-B's stopping rules can: a projected chord-Newton iteration on the
+    optimality conditions of the dual problem route! solves (src/router.jl:58-108),
+
+        Gⱼ(ν) = 0 for lⱼ < νⱼ,    Gⱼ(ν) ≥ 0 for νⱼ = lⱼ,    G(ν) = ∇f(obj, ν) + Ψ(ν),  l = lower_limit(obj),
+
+    starting from r.v.  NOT part of the reference (its route! ends where L-BFGS-B ends); it exists because L-BFGS-B's
+    line search works on the dual VALUE, whose rounding noise (a sum over 10⁶ pools) hides decreases below ~1e-15
+    relative -- on interior optima that leaves a stationarity residual of ~1e-6·max|Ψ| -- while the GRADIENT Ψ is
+    resolved to ~1e-12·max|Ψ|.  The iteration uses gradients only:
+
+        free set F = {j : not (νⱼ = lⱼ and Gⱼ > 0)},   ν_F ← max(l_F, ν_F − J_FF⁻¹ G_F),
+
+    J = `jacobian` (any reasonable approximation of the dual's Hessian: the limit point is where THIS backend's G
+    satisfies the conditions, whatever J is; only the rate depends on it) or `dual_jacobian(r)` at the start
+    (n_tokens + 1 sweeps).  Steps that do not reduce the residual are halved; the best iterate is kept.  Ends with
+    find_arb!(r, ν) like route! does (:106-107), so r.v / r.Δs / r.Λs / netflows(r) describe the polished point.
+    r.info["polish"] = {"residual0", "residual", "iterations", "sweeps"} (residual = max |G_F|, and −Gⱼ where a
+    variable on its bound has Gⱼ < 0)."""
+    n = r.v.size
+    lo = _obj.lower_limit(r.objective)
+    sweeps0 = r.n_sweeps
+    x = np.maximum(np.array(r.v, dtype=np.float64), lo)
+    J = dual_jacobian(r, x, rel_step) if jacobian is None else np.asarray(jacobian, dtype=np.float64)
+
+    def residual(x, G):
+        free = ~((x <= lo) & (G > 0.0))
+        return free, (float(np.max(np.abs(G[free]))) if free.any() else 0.0)
+
+    G, _, _ = _dual_gradient(r, x)
+    free, res = residual(x, G)
+    res0, done = res, 0
+    for _ in range(int(iters)):
+        if res == 0.0:
+            break
+        step = np.zeros(n)
+        step[free] = np.linalg.lstsq(J[np.ix_(free, free)], -G[free], rcond=1e-13)[0]
+        t, improved = 1.0, False
+        while t >= 1.0 / 64:
+            xt = np.maximum(x + t * step, lo)
+            Gt, _, _ = _dual_gradient(r, xt)
+            freet, rest = residual(xt, Gt)
+            if rest < res:
+                x, G, free, res, improved = xt, Gt, freet, rest, True
+                break
+            t *= 0.5
+        done += 1
+        if not improved:   # the rounding-noise floor of Ψ (or a kink the chord matrix cannot cross): keep the best iterate
+            break
+    r.v[:] = x
+    find_arb_(r, r.v)
+    info = dict(r.info) if isinstance(r.info, dict) else {}
+    info["polish"] = {"residual0": res0, "residual": res, "iterations": done, "sweeps": r.n_sweeps - sweeps0}
+    r.info = info
+    return None
+
+
 def netflows_(ψ, r: Router):
     """netflows!(ψ, r) -- src/router.jl:111-119: ψ = Σᵢ Aᵢ(Λᵢ − Δᵢ) for the latest sweep."""
     ψ[:] = r._psi

@@ -98,3 +98,72 @@ def test_dual_problem_matches_scipy(m, n, kind):
     assert abs(info["f"] - ref["f"]) <= 1e-9 * max(1.0, abs(ref["f"]))
     # not wildly more expensive than the Fortran lineage
     assert info["evaluations"] <= 3 * ref["info"]["funcalls"] + 10
+
+
+def _config5_problem(m, n, seed, threads=4):
+    """The dual of BASELINE config 5 in miniature (BasketLiquidation over BoundedProduct pools quoted around one price
+    vector: interior optimum), evaluated by the CPU restatement."""
+    b = synth.bounded_product_pools(m, n, seed=seed, consistent=True)
+    obj = cr.BasketLiquidation(1, synth.basket(n, seed=seed))
+    ps, oo = oracle_poolset([b], n), oracle_objective(obj)
+
+    def fg(v):
+        v = np.array(v, dtype=np.float64)
+        D, L = ps.sweep(v, threads)
+        G = oo.grad(v)
+        orc.grad_scatter(G, D, L, ps.Ai)
+        return oo.f(v) + orc.dual_acc(D, L, ps.Ai, v), G
+
+    return fg, oo.lower_limit(), np.ones(n) / n
+
+
+def _both_solvers(fg, lo, v0):
+    n, logs = v0.size, {"scipy": [], "native": []}
+
+    def logged(key):
+        def fun(x):
+            logs[key].append(np.array(x, dtype=np.float64))
+            return fg(x)
+        return fun
+
+    fmin_l_bfgs_b(logged("scipy"), v0.copy(), bounds=[(lo[j], orc.BOXED_INF) for j in range(n)], m=5, factr=1e1, pgtol=1e-5)
+    lbfgsb_minimize(logged("native"), v0.copy(), [(lo[j], None) for j in range(n)], m=5, factr=1e1, pgtol=1e-5,
+                    reference_boxed=True)
+    return logs["scipy"], logs["native"]
+
+
+def test_interior_optimum_trajectory_is_scipys_until_rounding_takes_over():
+    """where do csrc/lbfgsb.cpp and SciPy's L-BFGS-B (the translation of the Fortran 3.0 code the
+    reference calls, src/router.jl:60,105) part ways on an interior optimum?  Same callback, same start, same call
+    shape: NOWHERE as far as decisions go -- every evaluation point of the two solvers agrees to rounding
+    (≤ 1e-12 relative over the first 20 evaluations: Cauchy point, subspace step, initial step 1, every Moré-Thuente
+    trial), the difference then grows smoothly with the conditioning of the problem (≤ 1e-6 at every common
+    evaluation, no jump that a different branch would cause), and the runs end within a few evaluations ... or tens of
+    evaluations of each other, depending on which side of factr·eps the LAST decrease of the dual value falls (see the
+    next test).  scripts/solver_trace.py prints the full trace at any size."""
+    fg, lo, v0 = _config5_problem(60_000, 128, seed=1234)
+    a, b = _both_solvers(fg, lo, v0)
+    k = min(len(a), len(b))
+    assert k >= 40
+    dx = np.array([np.max(np.abs(a[i] - b[i]) / np.abs(a[i])) for i in range(k)])
+    assert np.all(dx[:20] <= 1e-12), dx[:20]
+    assert np.all(dx <= 1e-5), dx.max()
+    assert np.all(dx[-10:] <= 1e-6)          # still the same trajectory at the end of the shorter run
+
+
+def test_interior_optimum_evaluation_counts_match_scipys_on_average():
+    """On one market the two solvers' evaluation counts differ by up to ±30 % EITHER way (163 vs 123 on the device's
+    config 5 in round 3; 126 vs 148 on seed 1 here): the run ends when a decrease of the dual value falls below
+    factr·eps·|f| ≈ 1.6e-11, which is the rounding noise of a sum over the pools, and a side that misses that test by
+    a last-place digit spends up to 20 more evaluations per line search among values that differ in the last bits
+    (the reference's solver does the same).  There is no systematic difference: over a set of markets the mean counts
+    agree within a few per cent."""
+    counts = []
+    for seed in range(1, 9):
+        fg, lo, v0 = _config5_problem(30_000, 96, seed=seed)
+        a, b = _both_solvers(fg, lo, v0)
+        counts.append((len(a), len(b)))
+    counts = np.array(counts, dtype=np.float64)
+    ratio = counts[:, 1].mean() / counts[:, 0].mean()
+    print("evaluations scipy / native per market:", counts.astype(int).tolist(), "ratio of means", ratio)
+    assert 0.88 <= ratio <= 1.12
