@@ -80,7 +80,8 @@ int cfmm_ctx_create(int device_id, int32_t n_tokens, cfmm_ctx** out)
     // [n] v, [n+1] {psi, acc}, padding to a 128-byte boundary, then the output granules: 16 per fold
     // block = 2 per column, columns padded to a multiple of 8 (see fold_finish)
     c->gran_off = (size_t)((2 * c->n + 2 + 15) & ~15);
-    const size_t stage_words = c->gran_off + 2 * (size_t)((c->n + 1 + 7) & ~7);
+    c->flag_off = c->gran_off + 2 * (size_t)((c->n + 1 + 7) & ~7);
+    const size_t stage_words = c->flag_off + 16;
     HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), stage_words * sizeof(double), hipHostMallocMapped));
     std::memset(c->h_stage, 0, stage_words * sizeof(double));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_stage), c->h_stage, 0) != hipSuccess) {

@@ -304,7 +304,11 @@ int ensure_geometry(cfmm_ctx* c)
 //   want_host_out: the fold delivers {Ψ, acc} to the pinned staging buffer as self-validating granules (the caller
 //                  polls them: host_sweep_end / armed_wait) instead of writing d_out;
 //   arm_seq != 0:  pre-armed launch (SweepArgs::arm_word): v arrives later through c->d_arm.
-int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_out, uint64_t arm_seq)
+//   price_window:  what the host knows about v -- kPricesInWindow (host-pointer sweeps whose prices lie inside the
+//                  window of the fast arithmetic), kPricesOutside, or kPricesUnknown (device-pointer sweeps, pre-armed
+//                  launches: the fast kernel is launched and its blocks verify, see sweep_tiles).
+int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_out, uint64_t arm_seq,
+                  int price_window)
 {
     int rc = ensure_geometry(c);
     if (rc != CFMM_OK) return rc;
@@ -344,6 +348,11 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.arm_word = arm_word;
         a.arm_seq = arm_seq;
         a.arm_timeout = std::min<long long>(std::max<long long>(c->opt_arm_timeout_ms, 1), 10000) * 100000ll;   // ms -> ticks of the 100 MHz wall clock, at most 10 s
+        // sharded (cfmm_set_peers): a rank whose host is late by less than the peer timeout must not lose the evaluation --
+        // the other ranks' fold + gather launches wait that long for its granules anyway, so waiting for the price vector
+        // equally long turns a stalled host into a slow evaluation on every rank instead of a failed route on all of them
+        if (sharded) a.arm_timeout = std::max<long long>(a.arm_timeout, c->peer_timeout_ticks);
+        a.flags = c->d_stage ? reinterpret_cast<unsigned long long*>(c->d_stage + c->flag_off) : nullptr;
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double)
                               : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n, a.v_shift == 4 ? 1 : 0);
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -352,7 +361,13 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             eb = take_event(c);
             if (!ea || !eb) ea = eb = nullptr;
         }
-        auto fast_ok = [&](const Segment& s) { return (c->opt_fast_math != 0 && s.fast_ok != 0 && !gb) ? 1 : 0; };
+        // the kernel on the fast arithmetic: every pool constant of the launch inside the window (checked at upload), prices
+        // staged as {v, rcp(v)} pairs, and the prices themselves inside it as far as the host knows
+        bool fast = c->opt_fast_math != 0 && !gb && a.v_shift == 4 && price_window != kPricesOutside;
+        for (int k = 0; k < g.nseg && fast; ++k) {
+            const Segment& s = c->segs[(size_t)g.first + k];
+            fast = s.fast_ok != 0 && !(s.kind == CFMM_KIND_GEOMEAN && c->opt_geomean_exact != 0);
+        }
         const auto gbase_of = [&](const Segment& s) { return a.gtab_n ? s.gbase : -1; };   // -1: fees from the gamma array
         auto product_of = [&](const Segment& s) { return ProductPools{s.R, s.gamma, s.Ai, s.pk, gbase_of(s)}; };
         auto geomean_of = [&](const Segment& s) {
@@ -376,7 +391,6 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 const Segment& s = c->segs[(size_t)g.first + k];
                 MultiSeg& ms = ma.seg[k];
                 ms.kind = s.kind;
-                ms.fast_ok = fast_ok(s);
                 ms.m = s.m;
                 ms.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
                 ms.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
@@ -388,17 +402,16 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 default: ms.pools.u = univ3_of(s); break;
                 }
             }
-            LaunchCfg cfg{g.block, g.grid, lds, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, lds, fast, ea, eb};
             e = launch_multi(ma, cfg, materialize, c->stream);
         } else {
             const Segment& s = c->segs[(size_t)g.first];
             a.m = s.m;
-            a.fast_ok = fast_ok(s);
             a.Delta = materialize ? c->d_delta + s.trade_off : nullptr;
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
             a.Over = materialize ? c->d_over + s.trade_off : nullptr;
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
-            LaunchCfg cfg{g.block, g.grid, lds, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, lds, fast, ea, eb};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(product_of(s), a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN: e = launch_sweep(geomean_of(s), a, cfg, materialize, c->stream); break;
@@ -468,6 +481,28 @@ int check_prices(cfmm_ctx* c, const double* v)
     return CFMM_OK;
 }
 
+// every price in [2^-kFastExp, 2^kFastExp] (sweep.h): the host's half of the fast kernels' precondition
+bool prices_in_fast_window(const double* v, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        uint64_t bits;
+        std::memcpy(&bits, v + j, sizeof bits);
+        const int e = (int)((bits >> 52) & 0x7ff);
+        if (e < 1023 - kFastExp || e > 1023 + kFastExp) return false;
+    }
+    return true;
+}
+
+// Why did a sweep deliver NaN?  The blocks report through the sticky word (sweep.h kFlagWindow / kFlagGaveUp).
+unsigned long long take_flags(cfmm_ctx* c)
+{
+    if (!c->h_stage) return 0;
+    volatile unsigned long long* w = reinterpret_cast<volatile unsigned long long*>(c->h_stage + c->flag_off);
+    const unsigned long long f = *w;
+    if (f) *w = 0;
+    return f;
+}
+
 // First half of a host-pointer sweep: stage v, enqueue the evaluation (asynchronous).
 int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
 {
@@ -490,7 +525,8 @@ int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
     }
     // {Ψ, acc}: as output granules in the mapped pinned buffer when it can (polled by host_sweep_end), else d_out + a copy
     const bool want_host_out = zero_copy && c->opt_host_flag != 0;
-    int rc = enqueue_sweep(c, v_src, c->d_out, materialize, want_host_out);
+    int rc = enqueue_sweep(c, v_src, c->d_out, materialize, want_host_out, 0,
+                           prices_in_fast_window(v, c->n) ? kPricesInWindow : kPricesOutside);
     if (rc != CFMM_OK) return rc;
     if (!c->last_host_out)
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, (size_t)(c->n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -526,9 +562,14 @@ int take_host_out(cfmm_ctx* c)
         if (!std::isfinite(c->last_out[(size_t)j])) {
             c->have_out = false;
             (void)hipStreamSynchronize(c->stream);
+            const unsigned long long why = take_flags(c);
+            if (why & kFlagWindow) {   // (cannot happen on a host-pointer sweep: the host checked these prices)
+                c->dev_slow = true;
+                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}: a price lies outside the window of the fast arithmetic");
+            }
             if (!c->peers.empty())
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
-                                               "publish) or a shard overflowed", j);
+                                               "publish within CFMM_AMD_PEER_TIMEOUT_S) or a shard overflowed", j);
             return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: pool arithmetic overflowed", j);
         }
     c->have_out = true;
@@ -660,13 +701,17 @@ void armed_lost(cfmm_ctx* c, bool& retry)
 }
 
 // Wait for the signalled evaluation's granules.  CFMM_ERR_STATE with `lost` set: the device never delivered (host
-// stalled past arm_timeout_ms between two evaluations, or the device never saw the word): the caller may retry unarmed.
+// stalled past the arm timeout between two evaluations, or the device never saw the word): the caller may retry unarmed.
+// The bound: the device-side wait of the launch (arm_timeout_ms; on cfmm_set_peers contexts at least the peer timeout,
+// see enqueue_sweep) plus, on peers contexts, the time its fold + gather may legitimately wait for a slower rank.
 int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
 {
     lost = false;
     bool seen = false;
     const auto t0 = std::chrono::steady_clock::now();
-    const double limit = 2e-3 * (double)std::min<int64_t>(std::max<int64_t>(c->opt_arm_timeout_ms, 1), 10000) + 1.0;
+    const double arm_s = 1e-3 * (double)std::min<int64_t>(std::max<int64_t>(c->opt_arm_timeout_ms, 1), 10000);
+    const double peer_s = 1e-8 * (double)c->peer_timeout_ticks;
+    const double limit = c->peers.empty() ? 2.0 * arm_s + 1.0 : std::max(arm_s, peer_s) + peer_s + 2.0;
     for (long spins = 0;; ++spins) {
         if (granules_arrived(c, want)) { seen = true; break; }
         __builtin_ia32_pause();
@@ -676,13 +721,22 @@ int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
     std::atomic_thread_fence(std::memory_order_acquire);
     if (!seen) {
         armed_lost(c, lost);
-        return fail(c, CFMM_ERR_STATE, "armed evaluation did not complete (the device never saw its price vector)");
+        (void)take_flags(c);
+        return fail(c, CFMM_ERR_STATE, c->peers.empty()
+                        ? "armed evaluation did not complete (the device never saw its price vector)"
+                        : "armed evaluation did not complete within the arm + peer timeouts (this rank's launch never saw its "
+                          "price vector, or a peer never published)");
     }
-    // a block that gave up waiting for its prices poisons the dual column with NaN: the evaluation is lost, not wrong
+    // NaN in the dual column: the blocks say why through the sticky report word.  A launch that gave up waiting for its
+    // prices is a LOST evaluation (retried unarmed by the caller); anything else -- arithmetic overflow, a peer gather that
+    // timed out -- is reported by take_host_out as what it is.
     const double acc = c->h_stage[2 * c->n];
     if (acc != acc) {
-        armed_lost(c, lost);
-        return fail(c, CFMM_ERR_STATE, "armed evaluation gave up waiting for its price vector (host stalled longer than arm_timeout_ms)");
+        const unsigned long long why = take_flags(c);
+        if (why & kFlagGaveUp) {
+            armed_lost(c, lost);
+            return fail(c, CFMM_ERR_STATE, "armed evaluation gave up waiting for its price vector (host stalled longer than the arm timeout)");
+        }
     }
     int rc = take_host_out(c);
     if (rc != CFMM_OK) armed_cancel_single(c);
@@ -716,6 +770,13 @@ int armed_eval(cfmm_ctx* c, const double* v, bool* lost_out)
     if (lost_out) *lost_out = false;
     int rc = check_prices(c, v);
     if (rc != CFMM_OK) return rc;
+    if (!prices_in_fast_window(v, c->n)) {
+        // the waiting launch runs the fast arithmetic (its kernel was chosen before these prices existed): cancel it and
+        // evaluate launch-when-ready on the full-range kernels; the caller stops arming (prices this extreme stay extreme)
+        armed_cancel(c);
+        if (lost_out) *lost_out = true;
+        return is_parent(c) ? multi_host_sweep(c, v, false) : single_host_sweep(c, v, false);
+    }
     if (c->opt_debug_stall_ms > 0 && c->arm_pending) {   // test hook: the host "stalls" once while a launch waits for its prices
         std::this_thread::sleep_for(std::chrono::milliseconds(c->opt_debug_stall_ms));
         c->opt_debug_stall_ms = 0;
@@ -827,7 +888,16 @@ int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materializ
     CFMM_SINGLE_ONLY(c, "cfmm_sweep_dev");
     c->have_out = false; // results live on the device; the host copy is stale
     if (materialize) c->trade_v.clear();   // the library has not seen these prices
-    return enqueue_sweep(c, d_v, d_out, materialize != 0);
+    // Device-pointer sweeps run the fast kernels on trust: the library cannot see these prices.  A block that stages a
+    // price outside [2^-150, 2^150] (or NaN / 0 / inf) does not compute -- it poisons {psi, acc} with NaN and reports it.
+    // The next call finds the report and fails ONCE, saying so (nothing is enqueued); from then on this context's
+    // device-pointer sweeps run the full-range kernels, which treat such prices like the reference's arithmetic does.
+    if (!c->dev_slow && (take_flags(c) & kFlagWindow)) {
+        c->dev_slow = true;
+        return fail(c, CFMM_ERR_STATE, "an earlier device-pointer sweep met a price outside [2^-150, 2^150] and delivered NaN; "
+                                       "device-pointer sweeps on this context use the full-range arithmetic from now on: repeat the call");
+    }
+    return enqueue_sweep(c, d_v, d_out, materialize != 0, false, 0, c->dev_slow ? kPricesOutside : kPricesUnknown);
 }
 
 } // extern "C"

@@ -154,6 +154,9 @@ struct cfmm_ctx {
     double* h_stage = nullptr;
     double* d_stage = nullptr;    // device address of h_stage
     size_t gran_off = 0;          // first output granule in h_stage / d_stage (doubles)
+    size_t flag_off = 0;          // the sweeps' sticky report word (sweep.h kFlagWindow / kFlagGaveUp), its own 128-byte line
+    bool dev_slow = false;        // a device-pointer sweep met prices outside the window of the fast arithmetic: such sweeps
+                                  // run on the full-range kernels from then on (cfmm_sweep_dev)
     double* d_gtab = nullptr;     // [groups][kMaxFeeTable] fee tables of the launches (packed pool records)
     size_t gtab_cap = 0;
     // pre-armed evaluations of cfmm_route (sweep.h SweepArgs::arm_word): [n_pad] v, then the word, in FINE-GRAINED
@@ -250,8 +253,11 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
 
 // abi_sweep.cpp
 int ensure_geometry(cfmm_ctx* c);
+constexpr int kPricesUnknown = 0, kPricesInWindow = 1, kPricesOutside = 2;
 int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_out = false,
-                  uint64_t arm_seq = 0);
+                  uint64_t arm_seq = 0, int price_window = kPricesUnknown);
+bool prices_in_fast_window(const double* v, int n);
+unsigned long long take_flags(cfmm_ctx* c);
 int check_prices(cfmm_ctx* c, const double* v);
 int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize);
 int host_sweep_end(cfmm_ctx* c);

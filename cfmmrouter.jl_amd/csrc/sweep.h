@@ -91,8 +91,8 @@ struct SweepArgs {
     const double* gtab;          // the launch's fee table (device), staged in LDS when gtab_n > 0
     int gtab_n;
     int copies;                  // private bin copies per block (1 or one per wavefront)
-    int fast_ok;                 // 1: every pool constant of the segment lies in the kFastExp window (checked at upload)
-                                 //    and the option "fast_math" is on; the blocks still check the prices they stage
+    unsigned long long* flags;   // sticky report word in mapped host memory (or null): kFlagWindow / kFlagGaveUp, set by a block
+                                 //    that poisons its row (see sweep_tiles)
     int64_t m;                   // pools in this segment
     // Trade buffers of the segment (null when !materialize).  compact == 0: Delta[i] = {Δ₁, Δ₂}, Lambda[i] = {Λ₁, Λ₂}
     // (32 B written per pool).  compact == 1: at most one direction of a pool trades, so ONE 16-byte record goes
@@ -120,6 +120,8 @@ struct SweepArgs {
     long long arm_timeout;
 };
 constexpr unsigned long long kArmCancel = 1ull << 63;
+constexpr unsigned long long kFlagWindow = 1;   // a fast kernel staged a price outside [2^-kFastExp, 2^kFastExp]: rows poisoned
+constexpr unsigned long long kFlagGaveUp = 2;   // a pre-armed launch gave up waiting for its price vector: rows poisoned
 
 // One launch over up to kMaxMulti segments (sweep_multi).
 constexpr int kMaxMulti = 4;
@@ -130,7 +132,6 @@ union AnyPools {
 };
 struct MultiSeg {
     int kind;
-    int fast_ok;                 // see SweepArgs::fast_ok
     int64_t m;
     AnyPools pools;
     double2* Delta;
@@ -155,6 +156,8 @@ struct LaunchCfg {
     int block;                   // kMidBlock or kBigBlock
     int grid;
     size_t lds_bytes;
+    bool fast = false;           // the kernel on the fast arithmetic (sweep_kernels.hip, FASTK): every pool constant of the launch
+                                 // and -- as far as the host knows -- every price inside the kFastExp window
     hipEvent_t ev_start = nullptr; // both set: the launch is timed by the command processor
     hipEvent_t ev_stop = nullptr;  // (hipExtLaunchKernel), i.e. the kernel's own execution span
 };

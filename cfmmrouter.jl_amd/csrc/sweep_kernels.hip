@@ -711,23 +711,32 @@ __device__ __forceinline__ SweepLds carve_lds(const SweepArgs& a)
     return L;
 }
 
-// Pre-armed launch: one lane waits for the host's word (see SweepArgs::arm_word).  true = v is in place.
-__device__ __forceinline__ bool wait_armed(const SweepArgs& a)
+// Pre-armed launch: one lane waits for the host's word (see SweepArgs::arm_word).  1 = v is in place, 0 = the launch is
+// cancelled -- this sequence number with the cancel bit, or ANY later sequence number: the host has moved on (it
+// overwrites the one word while blocks of an abandoned launch may still be starting) --, -1 = gave up waiting.
+__device__ __forceinline__ int wait_armed(const SweepArgs& a)
 {
     const long long t0 = (long long)wall_clock64();
     for (;;) {
         const unsigned long long w = __hip_atomic_load(a.arm_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (w == a.arm_seq) return true;
-        if (w == (a.arm_seq | kArmCancel)) return false;
-        if ((long long)wall_clock64() - t0 > a.arm_timeout) return false;
+        if (w == a.arm_seq) return 1;
+        if ((w & ~kArmCancel) > a.arm_seq || w == (a.arm_seq | kArmCancel)) return 0;
+        if ((long long)wall_clock64() - t0 > a.arm_timeout) return -1;
         __builtin_amdgcn_s_sleep(1);
     }
 }
 
+// A block reports WHY it poisons its row (NaN in every column): one sticky word in mapped host memory, read by the
+// host when it meets a non-finite result (abi_sweep.cpp).  Rare paths only.
+__device__ __forceinline__ void report(const SweepArgs& a, unsigned long long bit)
+{
+    if (a.flags && threadIdx.x == 0) __hip_atomic_fetch_or(a.flags, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // bins <- 0, fee table and prices -> LDS, barrier.  Whole block.  Result (block-uniform): kStageLive unless this is a
-// pre-armed launch that was cancelled or gave up waiting for its prices; kStageFast when every staged price lies in the
-// window of the fast arithmetic.
-constexpr int kStageLive = 1, kStageFast = 2;
+// pre-armed launch that was cancelled or gave up waiting for its prices (then also kStageGaveUp); kStageFast when every
+// staged price lies in the window of the fast arithmetic.
+constexpr int kStageLive = 1, kStageFast = 2, kStageGaveUp = 4;
 template <int BLOCK, bool GBINS>
 __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& L)
 {
@@ -739,7 +748,7 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
     const int n_zero = a.copies * a.n_pad;                // LDS bins to clear
     const bool logs = a.need_logv != 0;
     const bool armed = a.arm_word != nullptr;             // kernel argument: block-uniform
-    bool live = true;
+    bool live = true, gave_up = false;
     if (armed) {
         // pre-armed launch: everything that does not need the prices first, then the wait
         for (int j = tid; j < n_zero; j += BLOCK) L.bins[j] = 0.0;
@@ -747,9 +756,10 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
             const double g = a.gtab[j];
             L.gtab[j] = make_double2(g, rcp_refined(g));
         }
-        if (tid == 0) L.flags[BLOCK / 64] = wait_armed(a) ? 1.0 : 0.0;
+        if (tid == 0) L.flags[BLOCK / 64] = (double)wait_armed(a);
         __syncthreads();
-        live = L.flags[BLOCK / 64] != 0.0;
+        live = L.flags[BLOCK / 64] > 0.0;
+        gave_up = L.flags[BLOCK / 64] < 0.0;
     }
     bool in_window = true;
     for (int j = tid; j < a.n; j += BLOCK) {
@@ -776,7 +786,7 @@ __device__ __forceinline__ int stage_prices(const SweepArgs& a, const SweepLds& 
     bool all_in = true;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) all_in = all_in && L.flags[w] != 0.0;
-    return (live ? kStageLive : 0) | (all_in ? kStageFast : 0);
+    return (live ? kStageLive : 0) | (all_in ? kStageFast : 0) | (gave_up ? kStageGaveUp : 0);
 }
 
 // One pool: prices from LDS, closed form, trade record, dual scalar, netflow bins.
@@ -917,10 +927,20 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
     }
 }
 
-template <class Ops, bool MAT, int BLOCK, bool GBINS>
+// FASTK selects the arithmetic of the WHOLE kernel (round 4).  Rounds 1-3 compiled both tile loops into every kernel and
+// chose per block; the two copies cost 12-36 VGPRs over the larger of the two alone (ProductTwoCoin 70 vs 56 / 58,
+// UniV3 84 vs 63 / 63, the fused materialising launch 116 vs 80 / 97: profiles/r04_kernel_resources.txt), i.e. one to
+// three wavefronts per SIMD.  Now the HOST picks the kernel: the fast one when every pool constant of the launch is
+// inside the window (Segment::fast_ok, checked at upload) and the prices are too -- which it knows for host-pointer
+// sweeps and for cfmm_route, and assumes for device-pointer sweeps.  Every block of a fast kernel still checks the
+// prices it stages; outside the window it does NOT compute: it poisons its row (NaN in every column -- an error, never
+// a wrong number) and reports kFlagWindow, upon which the library switches the context's device-pointer sweeps to the
+// full-range kernels (abi_sweep.cpp).
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
 __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
-                                              bool& live_out)
+                                              bool& poison)
 {
+    static_assert(!(GBINS && FASTK), "large-market mode runs on the compiler's sequences");
     double acc = 0.0;
     const int64_t stride = (int64_t)nblocks * BLOCK;
     const int64_t i0 = (int64_t)bid * BLOCK + threadIdx.x;
@@ -930,22 +950,24 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     typename Ops::Raw cur = {};
     if (left > 0) cur = ops.template load<GBINS>(i);
     const int staged = stage_prices<BLOCK, GBINS>(a, L);
-    live_out = (staged & kStageLive) != 0;
-    if (!live_out) {                                  // a pre-armed launch that is not needed (or gave up)
-        left = 0;
-        acc = __builtin_nan("");                      // poisons the dual column should anyone fold this row
+    poison = (staged & kStageLive) == 0;              // a pre-armed launch that is not needed (or gave up)
+    if (staged & kStageGaveUp) report(a, kFlagGaveUp);
+    if (FASTK && !poison && (staged & kStageFast) == 0) {
+        poison = true;                                // prices outside the window of this kernel's arithmetic
+        report(a, kFlagWindow);
     }
-    const bool fast = !GBINS && a.fast_ok != 0 && a.v_shift == 4 && (staged & kStageFast) != 0;   // block-uniform
-    if (fast) tile_loop<Ops, MAT, BLOCK, GBINS, !GBINS>(ops, a, L, cur, i, step, left, acc);
-    else tile_loop<Ops, MAT, BLOCK, GBINS, false>(ops, a, L, cur, i, step, left, acc);
+    if (poison) left = 0;
+    tile_loop<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, L, cur, i, step, left, acc);
     return acc;
 }
 
 // Block epilogue: fold the dual scalar (lanes by wave shuffles, waves through LDS, fixed order), fold
 // the bin copies in a fixed order and write the block's partial row.
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id)
+__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id, bool poison)
 {
+    const double nan = __builtin_nan("");
+    if (poison) acc = nan;                               // every column of a poisoned row is NaN: whoever folds it sees an error
     constexpr int kWaves = BLOCK / 64;
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -959,35 +981,35 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     for (int j = tid; j < n_cols; j += BLOCK) {
         double s = L.bins[j];
         for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
-        store_row(row + j, s);
+        store_row(row + j, poison ? nan : s);
     }
     if (tid == 0) {
         double s = L.wsum[0];
         for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
-        store_row(row + n_cols, s);
+        store_row(row + n_cols, poison ? nan : s);
     }
 }
 
 // One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
 // row goes to partials[row_id].
-template <class Ops, bool MAT, int BLOCK, bool GBINS = false>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
-    bool live;
-    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS>(ops, a, L, bid, nblocks, live);
-    finish_row<BLOCK, GBINS>(a, L, acc, row_id);
+    bool poison;
+    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, L, bid, nblocks, poison);
+    finish_row<BLOCK, GBINS>(a, L, acc, row_id, poison);
 }
 
-template <class Ops, bool MAT, int BLOCK, bool GBINS = false>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    sweep_body<Ops, MAT, BLOCK, GBINS>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
+    sweep_body<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Several segments (pool families) in ONE launch, so HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean /
 // UniV3 blocks are co-resident on every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
-template <bool MAT, int BLOCK, bool GBINS = false>
+template <bool MAT, int BLOCK, bool GBINS, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
     const int bidx = (int)blockIdx.x;
@@ -1015,20 +1037,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     const MultiSeg& sg = ma.seg[sidx];
     SweepArgs a = ma.common;
     a.m = sg.m;
-    a.fast_ok = sg.fast_ok;
     a.Delta = sg.Delta;
     a.Lambda = sg.Lambda;
     a.Over = sg.Over;
     a.gflow = sg.gflow;
     switch (sg.kind) {
     case 0:
-        sweep_body<ProductOps, MAT, BLOCK, GBINS>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
+        sweep_body<ProductOps, MAT, BLOCK, GBINS, FASTK>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
         break;
     case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
-        sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
+        sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS, FASTK>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
-        sweep_body<UniV3Ops, MAT, BLOCK, GBINS>(UniV3Ops{sg.pools.u}, a, local, nblocks, bidx);
+        sweep_body<UniV3Ops, MAT, BLOCK, GBINS, FASTK>(UniV3Ops{sg.pools.u}, a, local, nblocks, bidx);
         break;
     }
 }
@@ -1248,12 +1269,14 @@ size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab
     return words * sizeof(double);
 }
 
-template <class Ops>
+// Kernel instantiations (round 4: 52).  Per family {fast, full-range} x {materialising, fused} x {512, 1024 threads};
+// the reference-order GeometricMean forms and the large-market mode (GBINS, 512 threads) run full-range only.
+template <class Ops, bool FASTK>
 static hipError_t set_lds_attr(size_t bytes)
 {
     hipError_t e;
 #define CFMM_SET(MAT, B)                                                                              \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, B>),                \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<Ops, MAT, B, false, FASTK>),  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                  \
     if (e != hipSuccess) return e;
     CFMM_SET(true, kMidBlock) CFMM_SET(false, kMidBlock) CFMM_SET(true, kBigBlock) CFMM_SET(false, kBigBlock)
@@ -1261,24 +1284,26 @@ static hipError_t set_lds_attr(size_t bytes)
     return hipSuccess;
 }
 
-template <int B>
+template <int B, bool FASTK>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid), b(B);
-    if (mat) launch_k(&sweep_multi<true, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-    else launch_k(&sweep_multi<false, B, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+    if (mat) launch_k(&sweep_multi<true, B, false, FASTK>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+    else launch_k(&sweep_multi<false, B, false, FASTK>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
 }
 
 hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (ma.common.gflow) {   // large-market mode: kMidBlock only
+    if (ma.common.gflow) {   // large-market mode: kMidBlock, full-range arithmetic
         dim3 g(c.grid), b(kMidBlock);
-        if (mat) launch_k(&sweep_multi<true, kMidBlock, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-        else launch_k(&sweep_multi<false, kMidBlock, true>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        if (mat) launch_k(&sweep_multi<true, kMidBlock, true, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        else launch_k(&sweep_multi<false, kMidBlock, true, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
     } else if (c.block == kBigBlock) {
-        launch_multi_b<kBigBlock>(ma, c, mat, s);
+        if (c.fast) launch_multi_b<kBigBlock, true>(ma, c, mat, s);
+        else launch_multi_b<kBigBlock, false>(ma, c, mat, s);
     } else {
-        launch_multi_b<kMidBlock>(ma, c, mat, s);
+        if (c.fast) launch_multi_b<kMidBlock, true>(ma, c, mat, s);
+        else launch_multi_b<kMidBlock, false>(ma, c, mat, s);
     }
     return hipGetLastError();
 }
@@ -1286,36 +1311,51 @@ hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipSt
 hipError_t prepare_kernels(size_t max_lds_bytes)
 {
     hipError_t em;
-#define CFMM_SETM(MAT, B)                                                                             \
-    em = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_multi<MAT, B>),                     \
+#define CFMM_SETM(MAT, B, F)                                                                          \
+    em = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_multi<MAT, B, false, F>),           \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);         \
     if (em != hipSuccess) return em;
-    CFMM_SETM(true, kBigBlock) CFMM_SETM(false, kBigBlock) CFMM_SETM(true, kMidBlock) CFMM_SETM(false, kMidBlock)
+    CFMM_SETM(true, kBigBlock, true) CFMM_SETM(false, kBigBlock, true) CFMM_SETM(true, kMidBlock, true) CFMM_SETM(false, kMidBlock, true)
+    CFMM_SETM(true, kBigBlock, false) CFMM_SETM(false, kBigBlock, false) CFMM_SETM(true, kMidBlock, false) CFMM_SETM(false, kMidBlock, false)
 #undef CFMM_SETM
-    hipError_t e = set_lds_attr<ProductOps>(max_lds_bytes);
-    if (e != hipSuccess) return e;
-    e = set_lds_attr<GeoMeanOps>(max_lds_bytes);
-    if (e != hipSuccess) return e;
-    e = set_lds_attr<GeoMeanLogOps>(max_lds_bytes);
-    if (e != hipSuccess) return e;
-    return set_lds_attr<UniV3Ops>(max_lds_bytes);
+    hipError_t e;
+    if ((e = set_lds_attr<ProductOps, true>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<ProductOps, false>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanOps, false>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanLogOps, true>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanLogOps, false>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<UniV3Ops, true>(max_lds_bytes)) != hipSuccess) return e;
+    return set_lds_attr<UniV3Ops, false>(max_lds_bytes);
 }
 
-template <class Ops>
+template <class Ops, bool FASTK>
+static void launch_any_f(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    dim3 g(c.grid);
+    hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
+    if (c.block == kBigBlock) {
+        if (mat) launch_k(&sweep_kernel<Ops, true, kBigBlock, false, FASTK>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kBigBlock, false, FASTK>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
+    } else {
+        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, false, FASTK>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kMidBlock, false, FASTK>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+    }
+}
+
+template <class Ops, bool HAS_FAST = true>
 static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     if (a.m <= 0) return hipSuccess;
-    dim3 g(c.grid);
-    hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
-    if (a.gflow) { // large-market mode: kMidBlock only
-        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, true>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
-        else launch_k(&sweep_kernel<Ops, false, kMidBlock, true>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
-    } else if (c.block == kBigBlock) {
-        if (mat) launch_k(&sweep_kernel<Ops, true, kBigBlock, false>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
-        else launch_k(&sweep_kernel<Ops, false, kBigBlock, false>, g, dim3(kBigBlock), c.lds_bytes, s, e0, e1, ops, a);
+    if (a.gflow) { // large-market mode: kMidBlock, full-range arithmetic
+        dim3 g(c.grid);
+        hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
+        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, true, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kMidBlock, true, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+    } else if constexpr (HAS_FAST) {
+        if (c.fast) launch_any_f<Ops, true>(ops, a, c, mat, s);
+        else launch_any_f<Ops, false>(ops, a, c, mat, s);
     } else {
-        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
-        else launch_k(&sweep_kernel<Ops, false, kMidBlock, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        launch_any_f<Ops, false>(ops, a, c, mat, s);
     }
     return hipGetLastError();
 }
@@ -1326,7 +1366,7 @@ hipError_t launch_sweep(const ProductPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    if (p.reference_order) return launch_any(GeoMeanOps{p}, a, c, mat, s);
+    if (p.reference_order) return launch_any<GeoMeanOps, false>(GeoMeanOps{p}, a, c, mat, s);
     return launch_any(GeoMeanLogOps{p}, a, c, mat, s);
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)

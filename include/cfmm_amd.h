@@ -92,11 +92,14 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     Lambda1}, a two-coin trade has one direction -- plus overflow rows for pools whose four values
  *                     do not fit that form; cfmm_get_trades* / cfmm_trades_dev return the reference's rows bit for bit)
  *   arithmetic        "fast_math" (default 1: where every operand lies in [2^-150, 2^150] -- pool constants checked at
- *                     upload, prices by every block as it stages them -- divisions and square roots run the compiler's
+ *                     upload, prices by the host (host-pointer calls, cfmm_route) and again by every block as it stages
+ *                     them; the library then launches kernels in which divisions and square roots run the compiler's
  *                     own correctly-rounded instruction sequences WITHOUT their range scaffolding, and divisions by a
  *                     price or a fee reuse a reciprocal refined once per token / fee tier: same bits, ~half the
  *                     instructions; the log-space GeometricMean form -- within 1e-12 of the reference either way --
  *                     also evaluates its exponential with an own < 1 ulp polynomial instead of the device library's;
+ *                     anything outside the window runs the full-range kernels -- see cfmm_sweep_dev for the one case
+ *                     the library cannot decide beforehand;
  *                     0: the compiler's sequences and the library's exp everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
  *                     with pow in the reference's operation order instead of the default log-space form; both are within
  *                     1e-12 of the reference), "alternate" (default 1: consecutive evaluations walk every lane's tiles in
@@ -194,8 +197,13 @@ int cfmm_dual_value(cfmm_ctx* ctx, double* acc);
 /* ---- device-resident variants (stream / RCCL interop; no host round trip) -------------- */
 
 /* d_v: n_tokens device doubles (must be finite and > 0, src/cfmms.jl:129: the library cannot validate device
- * memory -- a NaN price propagates into the trades and psi of every pool that touches the token, exactly
- * as the reference's arithmetic does; non-positive prices give undefined trades).
+ * memory; non-positive prices give undefined trades).  The library cannot see these prices, so with "fast_math" (default)
+ * the sweep runs the fast-arithmetic kernels on trust, and their blocks verify: if any price lies outside
+ * [2^-150, 2^150] (NaN, 0 and infinities included) NOTHING is computed -- d_out is all NaN, an error, never a wrong
+ * number -- and the NEXT cfmm_sweep_dev on the context fails once with CFMM_ERR_STATE saying so; from then on the
+ * context's device-pointer sweeps run the full-range kernels, under which a NaN price propagates into the trades and
+ * psi of every pool that touches the token exactly as the reference's arithmetic does.  ("fast_math" = 0 selects those
+ * kernels from the start; host-pointer calls and cfmm_route choose per call, from the prices they are given.)
  * d_out: n_tokens+1 device doubles = {psi..., acc}: the
  * buffer a sharded run all-reduces (one collective per evaluation).  Asynchronous on the
  * context's stream.  materialize != 0: also write Delta/Lambda (find_arb! semantics). */

@@ -61,3 +61,32 @@ class OracleBackend:
 
     def reload(self, batches):
         self.ps = oracle_poolset(batches, self.n_tokens)
+
+
+def route_converged(obj, market, n, v0=None, nthreads=1, solver="native", router=None):
+    """Route-level parity BY CONVERGENCE.  Device side: route! (`solver`) on the HIP path, then
+    polish_ with the device's own finite-difference Jacobian.  CPU side: route_oracle (SciPy L-BFGS-B on the CPU
+    restatement), then the SAME polish_ code driven through the OracleBackend -- with the device's Jacobian as the chord
+    matrix, which only sets the rate: the point it converges to is where the RESTATEMENT's gradient satisfies the
+    optimality conditions (tests/test_polish_cpu.py::test_polish_with_a_foreign_chord_matrix...).  Returns the default-
+    tolerance distance, the converged distance (both max|ΔΨ| / max|Ψ|) and the polish records."""
+    r = router if router is not None else cr.Router(obj, market, n)
+    try:
+        cr.route_(r, v=v0, solver=solver)
+        psi_default, v_default, evals = cr.netflows(r).copy(), r.v.copy(), r.info["funcalls"]
+        J = cr.dual_jacobian(r)
+        cr.polish_(r, jacobian=J)
+        psi_dev, v_dev, pol_dev = cr.netflows(r).copy(), r.v.copy(), dict(r.info["polish"])
+    finally:
+        if router is None:
+            r.close()
+    ref = orc.route_oracle(oracle_objective(obj), oracle_poolset(market, n), v0=v0, nthreads=nthreads)
+    ro = cr.Router(obj, market, n, _backend=OracleBackend(n, market, nthreads))
+    ro.v[:] = ref["v"]
+    cr.polish_(ro, jacobian=J)
+    psi_ref = cr.netflows(ro)
+    return {"default": rel_to_max(psi_default, ref["psi"]), "converged": rel_to_max(psi_dev, psi_ref),
+            "v_converged": float(np.max(np.abs(v_dev - ro.v) / ro.v)),
+            "device_moved": rel_to_max(psi_default, psi_dev), "oracle_moved": rel_to_max(ref["psi"], psi_ref),
+            "evaluations_device": int(evals), "evaluations_oracle": int(ref["info"]["funcalls"]),
+            "polish_device": pol_dev, "polish_oracle": dict(ro.info["polish"]), "psi_scale": float(np.max(np.abs(psi_ref)))}

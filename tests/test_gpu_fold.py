@@ -302,30 +302,48 @@ def test_fast_math_is_bit_identical_and_falls_back_outside_its_window(scale_exp)
 
 
 @pytest.mark.parametrize("vscale", [2.0 ** 160, 2.0 ** -160, 1.0])
-def test_fast_math_price_window_is_checked_by_every_block(vscale):
-    """Prices outside the window (or a mix) are detected while the blocks stage them: the launch then takes the
-    compiler's division / square-root sequences -- same bits as fast_math = 0, also through cfmm_sweep_dev where the
-    library never sees the prices on the host."""
+def test_fast_math_price_window_is_checked_by_host_and_by_every_block(vscale):
+    """Prices outside the window of the fast arithmetic (round 4: the arithmetic is chosen per KERNEL, by the host).
+    Host-pointer calls see the prices and launch the full-range kernels: same bits as fast_math = 0 and as the CPU
+    restatement.  Device-pointer sweeps (cfmm_sweep_dev) run the fast kernels on trust and every block verifies the prices
+    it stages: outside the window nothing is computed -- {psi, acc} come back NaN, never a wrong number --, the next
+    call fails ONCE with CFMM_ERR_STATE, and from then on the context's device-pointer sweeps are full-range: exact."""
     import torch
     n = 64
     batches = [synth.product_pools(80_000, n, seed=611), synth.univ3_pools(9_000, n, 4, seed=612)]
     v = synth.sweep_prices(n, seed=613)
     v[::3] *= vscale                      # a third of the tokens far outside (price ratios up to 2^±160)
+    Do, Lo, psi_o, _ = oracle_sweep(batches, n, v, nthreads=8)
     res = {}
     for fast in (1, 0):
         be = cr.DeviceBackend(n, batches)
         be.ctx.set_option("fast_math", fast)
         try:
+            psi_h, _ = be.find_arb(v)                                  # host pointer: the library picks the kernel
+            Dh, Lh = be.trades()
+            np.testing.assert_array_equal(Dh, Do)
+            np.testing.assert_array_equal(Lh, Lo)
+            assert rel_to_max(psi_h, psi_o) <= 1e-12
             vt = torch.from_numpy(v).cuda()
             ot = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
             be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
             torch.cuda.synchronize()
+            if fast and vscale != 1.0:
+                assert np.all(np.isnan(ot.cpu().numpy()))             # every block refused: an error, not a number
+                with pytest.raises(cr.CFMMDeviceError, match="outside"):
+                    be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
+                be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)  # full-range kernels from here on
+                torch.cuda.synchronize()
             res[fast] = (ot.cpu().numpy(),) + be.trades()
+            v_in = synth.sweep_prices(n, seed=614)                     # and prices inside the window keep working
+            vt2 = torch.from_numpy(v_in).cuda()
+            be.ctx.sweep_dev(vt2.data_ptr(), ot.data_ptr(), False)
+            torch.cuda.synchronize()
+            assert rel_to_max(ot.cpu().numpy()[:n], oracle_sweep(batches, n, v_in, nthreads=8)[2]) <= 1e-12
         finally:
             be.close()
     for a, b in zip(res[1], res[0]):
         np.testing.assert_array_equal(a, b)
-    Do, Lo, _, _ = oracle_sweep(batches, n, v, nthreads=8)
     np.testing.assert_array_equal(res[1][1], Do)
     np.testing.assert_array_equal(res[1][2], Lo)
 
@@ -346,10 +364,17 @@ def test_device_pointer_sweep_with_invalid_prices_stays_in_bounds(bad):
     be = cr.DeviceBackend(n, batches)
     try:
         ot = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
-        for mat in (True, False):
-            be.ctx.sweep_dev(torch.from_numpy(vb).cuda().data_ptr(), ot.data_ptr(), mat)
-            torch.cuda.synchronize()
+        vbt = torch.from_numpy(vb).cuda()
         vt = torch.from_numpy(v).cuda()
+        be.ctx.sweep_dev(vbt.data_ptr(), ot.data_ptr(), True)
+        torch.cuda.synchronize()
+        if bad != -1.0:      # NaN, 0 and infinities are outside the window of the fast kernels: refused (all NaN), reported
+            assert np.all(np.isnan(ot.cpu().numpy()))     # once, and the context's device-pointer sweeps turn full-range
+            with pytest.raises(cr.CFMMDeviceError, match="outside"):
+                be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
+        for mat in (True, False):                          # (a negative price has an in-window exponent: garbage in, garbage out)
+            be.ctx.sweep_dev(vbt.data_ptr(), ot.data_ptr(), mat)
+            torch.cuda.synchronize()
         be.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), True)
         torch.cuda.synchronize()
         D, L = be.trades()

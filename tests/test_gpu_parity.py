@@ -14,7 +14,7 @@ import pytest
 import cfmmrouter_amd as cr
 from cfmmrouter_amd import synth
 from oracle import cfmm_oracle as orc
-from helpers import oracle_objective, oracle_poolset, oracle_sweep, rel_to_max
+from helpers import oracle_objective, oracle_poolset, oracle_sweep, rel_to_max, route_converged
 
 pytestmark = pytest.mark.gpu
 
@@ -513,22 +513,14 @@ def test_route_config5_interior_optimum(solver):
     assert rel_to_max(psi_at_ref, ref["psi"]) <= REDUCE_TOL
     np.testing.assert_array_equal(D_at_ref, ref["Delta"])
     np.testing.assert_array_equal(L_at_ref, ref["Lambda"])
-    # (2) The ALGORITHM's own scatter: both runs stop on factr = 1e1 (relative decrease of the dual <= 10 eps) with a
-    #     stationarity residual of ~1e-6 max|Ψ| left, and that residual -- not the sweep -- bounds how well two runs of
-    #     the SAME algorithm agree on Ψ*.  Measured here, not assumed: the CPU restatement is re-run from four starting
-    #     points perturbed by 1e-16 ... 1e-10 (relative), and the device's Ψ* must lie within 2x the hull of those runs
-    #     around the unperturbed one -- or within north_star's 1e-6 where the hull is tighter than that.
+    # (2) At default tolerances neither side pins Ψ* to 1e-6 here: both stop on factr = 1e1 (relative decrease of the
+    #     dual <= 10 eps) inside the rounding noise of the dual VALUE with a stationarity residual of ~1e-6 max|Ψ| left.
+    #     Sanity bound only; the parity statement is test_route_parity_by_convergence below.
     Ψ, scale = cr.netflows(r), np.max(np.abs(ref["psi"]))
-    v0 = np.ones(n) / n
-    hull = 0.0
-    for eps in (1e-16, 1e-15, 1e-13, 1e-10):
-        alt = orc.route_oracle(oracle_objective(obj), oracle_poolset(market, n), v0=v0 * (1 + eps * np.arange(n)),
-                               nthreads=_threads())
-        hull = max(hull, np.max(np.abs(alt["psi"][1:] - ref["psi"][1:])) / scale)
     dev = np.max(np.abs(Ψ[1:] - ref["psi"][1:])) / scale
-    print(f"config5 interior ({solver}): device vs oracle {dev:.2e}, oracle's own scatter hull {hull:.2e}, "
+    print(f"config5 interior ({solver}): device vs oracle at default tolerances {dev:.2e}, "
           f"|v*-v*ref|/|v*ref| {np.max(np.abs(r.v - ref['v']) / ref['v']):.2e}")
-    assert dev <= max(ROUTE_TOL, 2 * hull)
+    assert dev <= 1e-5
     res_dev = np.max(np.abs(Ψ[1:] + obj.Δin[1:])) / scale
     res_ref = np.max(np.abs(ref["psi"][1:] + obj.Δin[1:])) / scale
     assert res_dev <= 1e-5 and res_ref <= 1e-5
@@ -548,6 +540,47 @@ def test_route_config5_interior_optimum(solver):
     np.testing.assert_array_equal(r.Δs, Do)
     np.testing.assert_array_equal(r.Λs, Lo)
     r.close()
+
+
+CONVERGED_TOL = 1e-8   # of max|Ψ|: the two converged netflow vectors (measured: 1e-14 .. 1e-12)
+
+
+@pytest.mark.parametrize("solver", ["native", "scipy"])
+@pytest.mark.parametrize("name", ["config5_300k", "config5_1m", "univ3_ticks_1m", "config4shard", "config3_1m"])
+def test_route_parity_by_convergence(name, solver):
+    """Route-level parity proven by convergence (src/router.jl:58,105, src/objectives.jl:92-129).
+    route! on the HIP path and on the CPU restatement end up to 2e-6·max|Ψ| apart at the reference's tolerances on the
+    interior optima (config 5, multi-tick UniV3) and up to 8e-7 on the arbitrage configs -- L-BFGS-B's stopping slack on
+    each side, not a difference of the evaluations: tightening BOTH sides with the same gradient-only polish
+    (cfmmrouter.jl_amd/router.py::polish_) makes the two Ψ* agree to <= 1e-8 (measured 1e-14 .. 1e-12).  factr -> 0 /
+    pgtol -> 1e-9 do not do that: L-BFGS-B's line search compares dual VALUES, whose rounding noise (~1e-15 relative, a
+    sum over 10^6 pools) hides the remaining decrease, and the run ends in ABNORMAL_TERMINATION_IN_LNSRCH at the same
+    residual.  At default tolerances only a sanity bound is asserted."""
+    if solver == "scipy" and name not in ("config5_300k", "config4shard"):
+        pytest.skip("the SciPy-driven loop is exercised on two shapes; the library's own solver on all")
+    n = 512 if name == "config4shard" else 256
+    if name.startswith("config5"):
+        market = [synth.bounded_product_pools(300_000 if name.endswith("300k") else 1_000_000, n, seed=1234, consistent=True)]
+    elif name == "univ3_ticks_1m":
+        market = [synth.univ3_ragged_pools(1_000_000, n, seed=1234)]
+    elif name == "config4shard":
+        market = [synth.product_pools(500_000, n, seed=1234)]
+    else:
+        market = [synth.product_pools(500_000, n, seed=1234), synth.geomean_pools(500_000, n, seed=1234)]
+    basket = name.startswith("config5") or name.startswith("univ3")
+    obj = cr.BasketLiquidation(1, synth.basket(n, seed=1234)) if basket else cr.LinearNonnegative(synth.linear_prices(n, seed=1234))
+    out = route_converged(obj, market, n, v0=None if basket else np.ones(n), nthreads=_threads(), solver=solver)
+    print(f"{name} ({solver}): default {out['default']:.2e} -> converged {out['converged']:.2e} (v* {out['v_converged']:.1e}); "
+          f"route! ended {out['device_moved']:.1e} (device) / {out['oracle_moved']:.1e} (CPU restatement) from its own converged "
+          f"point; evaluations {out['evaluations_device']} / {out['evaluations_oracle']}; residuals "
+          f"{out['polish_device']['residual0']:.1e} -> {out['polish_device']['residual']:.1e} / "
+          f"{out['polish_oracle']['residual0']:.1e} -> {out['polish_oracle']['residual']:.1e}")
+    assert out["converged"] <= CONVERGED_TOL
+    assert out["default"] <= 1e-5
+    # each side's route! result lies within ITS OWN stopping slack of the common converged point
+    assert out["default"] <= 1.5 * (out["device_moved"] + out["oracle_moved"]) + CONVERGED_TOL
+    for pol in (out["polish_device"], out["polish_oracle"]):
+        assert pol["residual"] <= 1e-9 * out["psi_scale"]
 
 
 @pytest.mark.parametrize("kind", ["arb", "basket", "mixed"])
