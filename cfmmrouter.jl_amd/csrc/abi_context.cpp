@@ -248,6 +248,10 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
 int cfmm_get_option(const cfmm_ctx* c, const char* key, int64_t* value)
 {
     if (!c || !value) return CFMM_ERR_INVALID_ARG;
+    if (key && !std::strcmp(key, "peer_seq")) {   // read-only: sharded sweeps performed on the current peer buffers
+        *value = (int64_t)c->peer_seq;            // (cfmm_set_peers' `seq` to continue from; ranks re-align on the maximum)
+        return CFMM_OK;
+    }
     int64_t* slot = option_slot(const_cast<cfmm_ctx*>(c), key);
     if (!slot) return fail(c, CFMM_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
     *value = *slot;

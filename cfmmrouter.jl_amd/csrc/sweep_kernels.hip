@@ -535,8 +535,9 @@ struct UniV3Ops {
     static constexpr int kCurEmpty = 0, kCurPartial = 1, kCurDrained = 2;
     template <bool FAST>
     __device__ __forceinline__ bool head(const Raw& r, const Px& px, Trade& t, bool& up, double& g, double& yg, double& price,
-                                         double& yp, double& sd, double& sl, int& cur) const
+                                         double& yp, double& sd, double& sl, int& cur, bool& inside) const
     {
+        inside = false;
         const double cp = r.pg.x;
         g = r.pg.y;
         yg = r.yg;
@@ -566,6 +567,10 @@ struct UniV3Ops {
                 } else {
                     sl = s_out - (FAST ? fast_sqrt(price * k0) : sqrt(price * k0));   // :334
                     sd = dd;
+                    // the target price lies INSIDE this tick by more than a relative 2^-29: sqrt(k/price) is below its
+                    // value at the tick's far boundary, s_in + δmax, by more than 2^-30 of it -- no later tick can be
+                    // entered (its s_in is the square root at a boundary price beyond this one's; rounding is monotone)
+                    inside = dd < dmax - 0x1p-30 * (s_in + dmax);
                 }
             }
         }
@@ -586,17 +591,20 @@ struct UniV3Ops {
     // reference's tick-by-tick evaluation takes over (one partially filled tick, normally), and it goes on to the
     // following tick only inside a 2^-40 band around that tick's threshold -- outside it the next tick cannot be
     // entered: its s_in is sqrt(k/p⁺) with p⁺ <= this tick's far boundary < price, and rounding is monotone.  A pool
-    // that ends inside its current tick (kCurPartial) runs the plain walk (it stops at the first list tick).
+    // that ends inside its current tick (kCurPartial) reads no list at all (round 4; `inside` in head()) unless its
+    // target price is within 2^-29 of the tick's far boundary, where the plain walk decides (it stops at the first list tick).
     template <bool FAST>
     __device__ __forceinline__ int solve_dir(const Raw& r, const Px& px, double& d, double& l, Trade& t) const
     {
-        bool up;
+        bool up, inside;
         int cur;
         double g, yg, price, yp, sd, sl;
         d = l = 0.0;
-        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl, cur)) return t.d1 != t.d1 ? kDirBoth : kDirNone;   // (NaN price: t is all-NaN)
+        if (!head<FAST>(r, px, t, up, g, yg, price, yp, sd, sl, cur, inside)) return t.d1 != t.d1 ? kDirBoth : kDirNone;   // (NaN price: t is all-NaN)
         const int begin = up ? r.walk.x : r.walk.z;
-        const int count = up ? r.walk.y : r.walk.w;
+        // a pool that ends well inside its current tick (the common case) touches no list at all; the reference's next
+        // find_arb_pos would return zeros and break (:363-365).  Within 2^-29 of the far boundary the plain walk decides.
+        const int count = inside ? 0 : (up ? r.walk.y : r.walk.w);
         int j = 0;
         const bool jump = cur != kCurPartial && count > 0;
         TickRec rec;

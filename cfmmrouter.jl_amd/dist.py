@@ -98,6 +98,72 @@ def open_peer_buffers(ctx, group, device):
     return None
 
 
+class PeerGuard:
+    """Collective safety net of a router whose all-reduce lives inside the library (cfmm_set_peers).
+
+    * `self_check()` -- right after the mappings are opened, before anything depends on them: a few sharded sweeps at a
+      synthetic price vector against the same sweeps all-reduced through torch.distributed (RCCL); every rank votes
+      (MIN) and ALL ranks keep or drop the in-library exchange together.  What no single-GPU test can show -- that
+      fine-grained stores become visible to a peer's system-scope loads over xGMI the way they do within one GPU -- is
+      thereby checked on the machine the router runs on, and a disagreement costs the fast path, not the route.
+    * `vote(ok)` / `resync()` -- after a native route!: if ANY rank's call failed (a lost pre-armed hand-over, a peer
+      that did not publish in time), all ranks re-align their exchange sequence numbers on the maximum, switch
+      pre-arming off and repeat the route launch-when-ready; only a second collective failure is raised."""
+
+    def __init__(self, ctx, peers, world, rank, group, device):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.ctx, self.peers, self.world, self.rank, self.group = ctx, peers, world, rank, group
+        self.device = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.cuda = device
+
+    def vote(self, ok: bool) -> bool:
+        t = self._torch.tensor([1.0 if ok else 0.0], dtype=self._torch.float64, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+        return float(t.item()) == 1.0
+
+    def resync(self):
+        t = self._torch.tensor([float(self.ctx.get_option("peer_seq"))], dtype=self._torch.float64, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+        self.ctx.set_peers(self.peers.ptrs, self.world, self.rank, int(t.item()) + 2)   # stale granules carry older tags
+
+    def self_check(self, n_tokens, sweeps=3, rtol=1e-12):
+        import os
+        torch, dist = self._torch, self._dist
+        ok = True
+        try:
+            with torch.cuda.device(self.cuda):
+                j = torch.arange(n_tokens, dtype=torch.float64, device=self.cuda)
+                out = torch.zeros(n_tokens + 1, dtype=torch.float64, device=self.cuda)
+                ref = torch.zeros(n_tokens + 1, dtype=torch.float64, device=self.cuda)
+                stream = torch.cuda.current_stream(self.cuda)
+                self.ctx.set_stream(stream.cuda_stream)
+                for k in range(sweeps):
+                    v = torch.exp(0.2 * torch.sin(j * (0.7 + k)))            # positive, off the no-arbitrage manifold
+                    self.ctx.set_peers(self.peers.ptrs, self.world, self.rank, k)
+                    self.ctx.sweep_dev(v.data_ptr(), out.data_ptr(), False)
+                    self.ctx.set_peers([], 0, 0, 0)
+                    self.ctx.sweep_dev(v.data_ptr(), ref.data_ptr(), False)
+                    stream.synchronize()
+                    r = ref.cpu() if self.device.type == "cpu" else ref
+                    dist.all_reduce(r, group=self.group)
+                    r = r.to(self.cuda)
+                    got_ok = bool(torch.isfinite(out).all()) and \
+                        float((out - r).abs().max()) <= rtol * max(float(r.abs().max()), 1e-300)
+                    ok = ok and got_ok
+                self.ctx.reset_stream()
+        except Exception:
+            ok = False
+            try:
+                self.ctx.reset_stream()
+            except Exception:
+                pass
+        if os.environ.get("CFMM_AMD_PEER_SELFTEST_FAIL") == str(self.rank):   # test hook: this rank reports a disagreement
+            ok = False
+        return self.vote(ok), sweeps
+
+
 def shard_range(m: int, rank: int, world: int):
     """Contiguous block [lo, hi) of m items owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(int(m), int(world))
@@ -181,11 +247,13 @@ class ShardedBackend:
 
 
 def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None, group=None,
-                  already_sharded=False, _local_backend_factory=None):
+                  already_sharded=False, _local_backend_factory=None, self_check=True):
     """Router(objective, cfmms, n_tokens) whose pools are block-partitioned over the ranks of a
     torch.distributed process group.  `cfmms` is the FULL market on every rank (or this rank's
     shard with already_sharded=True).  r.Δs / r.Λs / r.cfmms describe the local shard; r.v and
-    netflows(r) are global and identical on all ranks."""
+    netflows(r) are global and identical on all ranks.  r.collective says which all-reduce the router ended up with:
+    the in-library peer exchange (after its start-up check against torch.distributed, `PeerGuard.self_check`) or the
+    torch.distributed fall-back."""
     import torch.distributed as dist
 
     rank = dist.get_rank(group) if rank is None else rank
@@ -209,7 +277,19 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
             with torch.cuda.device(dev):
                 peers = open_peer_buffers(backend.ctx, group, torch.device("cuda", dev))
             if peers is not None:
-                backend.ctx.set_peers(peers.ptrs, world, rank, 0)   # the granules are fresh
-                backend.peer = peers   # keeps the mappings alive
-                return Router(objective, local, n_tokens, _backend=backend)
-    return Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))
+                # the exchange is checked against RCCL on THIS machine before anything depends on it (collective vote:
+                # all ranks keep it or all drop it), and the router keeps the guard for collective retries of route!
+                guard = PeerGuard(backend.ctx, peers, world, rank, group, torch.device("cuda", dev))
+                good, done = guard.self_check(n_tokens) if self_check else (True, 0)
+                if good:
+                    backend.ctx.set_peers(peers.ptrs, world, rank, done)
+                    backend.peer = peers   # keeps the mappings alive
+                    r = Router(objective, local, n_tokens, _backend=backend)
+                    r._guard = guard
+                    r.collective = "peer all-reduce inside the library (cfmm_set_peers), checked against torch.distributed"
+                    return r
+                backend.ctx.set_peers([], 0, 0, 0)
+                peers.close(collective=True)      # every rank is here (the vote was collective)
+    r = Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))
+    r.collective = "all-reduce through torch.distributed (RCCL)"
+    return r

@@ -22,7 +22,7 @@ import math
 import numpy as np
 
 from . import objectives as _obj
-from ._lib import KIND_GEOMEAN, KIND_PRODUCT, KIND_UNIV3, ArgumentError, Context
+from ._lib import KIND_GEOMEAN, KIND_PRODUCT, KIND_UNIV3, ArgumentError, CFMMDeviceError, Context
 from .cfmms import CFMM, PoolBatch, _upload
 
 
@@ -248,8 +248,31 @@ def _route_native(r: Router, v, m, factr, pgtol, maxfun, maxiter):
             kind, vec, idx = OBJ_BASKET_LIQUIDATION, obj.Δin, obj.i - 1
         else:
             raise ArgumentError("solver='native' knows LinearNonnegative and BasketLiquidation objectives")
-        vout, psi, info = r._backend.ctx.route(kind, vec, idx, v0=v, m=m, factr=factr, pgtol=pgtol,
-                                               maxfun=maxfun, maxiter=maxiter)
+        ctx, guard = r._backend.ctx, getattr(r, "_guard", None)
+        call = lambda: ctx.route(kind, vec, idx, v0=v, m=m, factr=factr, pgtol=pgtol, maxfun=maxfun, maxiter=maxiter)
+        if guard is None:
+            vout, psi, info = call()
+        else:
+            # sharded (cfmm_set_peers): the ranks run this call in lockstep.  If ANY rank's call fails -- a lost pre-armed
+            # hand-over, a peer that did not publish within the time limit -- every rank learns it through one vote,
+            # the exchange is re-aligned, pre-arming goes off and the route is repeated launch-when-ready on all ranks.
+            res = err = None
+            try:
+                res = call()
+            except RuntimeError as e:      # CFMM_ERR_STATE (RuntimeError) or a HIP failure (CFMMDeviceError, its subclass)
+                err = e
+            if not guard.vote(res is not None):
+                guard.resync()
+                ctx.set_option("armed", 0)
+                res = err = None
+                try:
+                    res = call()
+                except RuntimeError as e:
+                    err = e
+                if not guard.vote(res is not None):
+                    raise err if err is not None else CFMMDeviceError("sharded route! failed on another rank")
+                r.collective_retries = getattr(r, "collective_retries", 0) + 1
+            vout, psi, info = res
         r.v[:] = vout
         r._psi, r._acc = psi, r._backend.ctx.dual_value()
         r._trades_stale = True

@@ -19,6 +19,8 @@ from cfmmrouter_amd import synth
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+if "--selftest-fail" in sys.argv:     # ONE rank reports a disagreement in the start-up check: all ranks must fall back
+    os.environ["CFMM_AMD_PEER_SELFTEST_FAIL"] = "1"
 n = 512
 market = [synth.product_pools(300_000, n, seed=81), synth.geomean_pools(100_000, n, seed=82),
           synth.bounded_product_pools(60_000, n, seed=83, consistent=True)]
@@ -31,12 +33,26 @@ if isinstance(r._backend, cr.DeviceBackend):
     # multi-device contexts that list a device twice.)
     r._backend.ctx.set_option("armed", 0)
 out = {"world": world, "in_library_collective": isinstance(r._backend, cr.DeviceBackend),
-       "buffers": type(getattr(r._backend, "peer", None)).__name__}
+       "buffers": type(getattr(r._backend, "peer", None)).__name__, "collective": r.collective,
+       "guard": hasattr(r, "_guard")}
+if "--fail-route-once" in sys.argv and isinstance(r._backend, cr.DeviceBackend) and rank == world - 1:
+    # the last rank's first native route! fails BEFORE it publishes anything: the other ranks run into the peer time-out,
+    # every rank votes, the exchange is re-aligned and the route repeated (PeerGuard, router.py::_route_native)
+    real_route, state = r._backend.ctx.route, {"failed": False}
+
+    def flaky_route(*a, **kw):
+        if not state["failed"]:
+            state["failed"] = True
+            raise cr.CFMMDeviceError("injected failure (test)")
+        return real_route(*a, **kw)
+
+    r._backend.ctx.route = flaky_route
 v = synth.sweep_prices(n, seed=84)
 cr.find_arb_(r, v)
 psi_fixed = cr.netflows(r).copy()
 cr.route_(r, v=np.ones(n), solver="native")
 psi_native, v_native, ev_native = cr.netflows(r).copy(), r.v.copy(), r.info["funcalls"]
+out["collective_retries"] = getattr(r, "collective_retries", 0)
 cr.route_(r, v=np.ones(n), solver="scipy")
 psi_scipy = cr.netflows(r).copy()
 gathered = [None] * world

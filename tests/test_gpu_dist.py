@@ -94,6 +94,31 @@ def test_sharded_route_across_processes_sharing_one_gpu(world):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("IPC_RANKS ")][-1][len("IPC_RANKS "):])
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"ipc_ranks_world{world}.json"), "w"), indent=1)
     assert out["world"] == world and out["in_library_collective"] and out["buffers"] == "IpcPeers"
+    assert out["guard"] and "checked against torch.distributed" in out["collective"] and out["collective_retries"] == 0
+    assert out["ranks_bit_identical"] and out["pools_total"] == 460_000
+    assert out["fixed_v_rel_diff"] <= 1e-13
+    assert out["route_native_rel_diff"] <= 1e-6 and out["route_scipy_rel_diff"] <= 1e-6 and out["evaluations"] >= 5
+
+
+@pytest.mark.parametrize("mode", ["selftest-fail", "fail-route-once"])
+def test_sharded_router_guard_across_processes(mode):
+    """VERDICT r3 item 3, in the LIBRARY path (dist.py::ShardedRouter), two processes on the one GPU:
+    selftest-fail   -- the start-up check of the in-library exchange against torch.distributed is made to disagree on ONE
+                       rank: the vote is collective, so BOTH ranks drop the exchange and route through the
+                       torch.distributed all-reduce -- same results;
+    fail-route-once -- one rank's native route! fails before it publishes: the other rank runs into the peer time-out, both
+                       vote, re-align the exchange, switch pre-arming off and repeat the route -- same results."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ipc_ranks_worker.py"), "--" + mode]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CFMM_AMD_PEER_TIMEOUT_S="3")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("IPC_RANKS ")][-1][len("IPC_RANKS "):])
+    if mode == "selftest-fail":
+        assert not out["in_library_collective"] and "torch.distributed" in out["collective"] and not out["guard"]
+    else:
+        assert out["in_library_collective"] and out["guard"] and out["collective_retries"] == 1
     assert out["ranks_bit_identical"] and out["pools_total"] == 460_000
     assert out["fixed_v_rel_diff"] <= 1e-13
     assert out["route_native_rel_diff"] <= 1e-6 and out["route_scipy_rel_diff"] <= 1e-6 and out["evaluations"] >= 5
