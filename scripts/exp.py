@@ -8,7 +8,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import numpy as np, torch
 import cfmmrouter_amd as cr
 from cfmmrouter_amd import synth
-import bench
+from benchlib import workloads as bench
 
 name = sys.argv[1]
 desc, n, _ = bench.WORKLOADS[name]

@@ -1,13 +1,15 @@
 #!/bin/bash
-# One GPU-box session for the judged artefacts: parity tests, bench lines, rocprofv3 kernel stats, PMC traffic, SQ counters.
-# Every step is bounded.  Outputs go to gpurun_out/ (scratch); scripts/collect_profiles.py copies the
-# summaries into profiles/ (tracked).
-#   usage: [TESTS=1] [FULL="config3 ..."] [PROF="config3 ..."] [PMC="config3"] [PMCX="config3"] bash scripts/gpu_round.sh
+# One GPU-box session for the judged artefacts: parity tests, bench lines, rocprofv3 kernel stats, PMC traffic, SQ counters,
+# option A/Bs, route! kernel gaps, the reference's benchmark grid.  Every step is bounded.  Outputs go to gpurun_out/
+# (scratch); scripts/collect_profiles.py copies the summaries into profiles/ (tracked).
+#   usage: [TESTS=1] [FULL="config3 ..."] [PROF="config3 ..."] [PMC="config3"] [PMCX="config3"] [GAPS="config3 config5"]
+#          [AB="workload:spec;spec ..."] [GRID=1] bash scripts/gpu_round.sh
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 if [ -n "$TESTS" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 < /dev/null; tail -4 gpurun_out/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/smoke.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "parity_by_convergence" 2>&1 < /dev/null | grep -E "default|passed|failed" > gpurun_out/route_convergence.txt; cat gpurun_out/route_convergence.txt
 fi
 for w in $FULL; do
   steps=100; [ "$w" = "config3" ] && steps=20      # config3 exactly as the driver runs it (--steps 20 --warmup 5)
@@ -15,6 +17,18 @@ for w in $FULL; do
   timeout 500 python bench.py --steps $steps --warmup $warm --workload $w > gpurun_out/benchfull_$w.log 2>&1 < /dev/null
   timeout 20 python scripts/show_bench.py gpurun_out/benchfull_$w.log $w < /dev/null
 done
+if [ -n "$GRID" ]; then
+  timeout 900 python bench.py --workload scaling > gpurun_out/benchfull_scaling.log 2>&1 < /dev/null; tail -c 600 gpurun_out/benchfull_scaling.log
+fi
+if [ -n "$AB" ]; then   # AB="product1m:;max_grid=512 config3:;max_grid=768"  (specs separated by ';', '' = defaults), warm then HBM-resident
+  for item in $AB; do
+    w=${item%%:*}; specs=${item#*:}
+    IFS=';' read -ra S <<< "$specs"
+    timeout 300 python scripts/exp.py $w "${S[@]}" >> gpurun_out/ab_options.txt 2>&1 < /dev/null
+    COLD=1 timeout 400 python scripts/exp.py $w "${S[@]}" >> gpurun_out/ab_options.txt 2>&1 < /dev/null
+  done
+  cat gpurun_out/ab_options.txt
+fi
 cd /tmp && export TMPDIR=/tmp
 for w in $PROF; do
   for mode in warm cold; do
@@ -33,7 +47,18 @@ for w in $PMCX; do   # occupancy / stall mix / LDS conflicts / L2 hit rate of th
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/pmcx_${w}_sq -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmcx_${w}_sq.log 2>&1 < /dev/null
   timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmcx_${w}_tcc -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmcx_${w}_tcc.log 2>&1 < /dev/null
 done
+if [ -n "$GAPS" ]; then   # one warm cfmm_route under the kernel trace, pre-armed and launch-when-ready
+  {
+  echo "# rocprofv3 --kernel-trace of scripts/route_gaps.py once (one warm cfmm_route), summarised by scripts/route_gaps.py gaps"
+  for w in $GAPS; do for a in 1 0; do
+    rm -rf $R/gpurun_out/rt_${w}_$a
+    timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/rt_${w}_$a -o t -- python $R/scripts/route_gaps.py once $w $a > $R/gpurun_out/rt_${w}_$a.log 2>&1 < /dev/null
+    python $R/scripts/route_gaps.py gaps $R/gpurun_out/rt_${w}_$a "$w a=$a"
+  done; done
+  } > $R/gpurun_out/route_kernel_gaps.txt 2>&1
+  cat $R/gpurun_out/route_kernel_gaps.txt
+fi
 cd $R
 [ -n "$PMC" ] && timeout 60 python scripts/pmc_summary.py gpurun_out $PMC < /dev/null
-[ -n "$PMCX" ] && timeout 60 python scripts/pmc_extra_summary.py < /dev/null
+[ -n "$PMCX" ] && timeout 60 python scripts/pmc_summary.py --extra < /dev/null
 true

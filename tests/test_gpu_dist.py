@@ -80,6 +80,38 @@ def test_bench_single_process_multi_device_and_cold_only():
     assert 0.2 < line["roofline"]["frac"] < 1.0
 
 
+def test_bench_default_line_and_reference_grid():
+    """The driver's command (N = 1, config3) carries the round-4 fields -- parity by convergence, the fraction of the bus
+    from live PMC bytes (or the committed fall-back), an HBM-resident step without kernel events -- and
+    `--workload scaling` reproduces the reference's own benchmark grid (benchmark/scaling.jl:8-38): 30 points."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-1500:], r.stderr[-2000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    roof, par = line["roofline"], line["parity"]
+    assert line["n_gpus"] == 1 and line["config"]["workload"].startswith("config3")
+    assert roof["bound"] == "hbm" and 0.2 < roof["frac"] < 1.0 and roof["cold"]["ms_per_step"] > 0
+    assert roof["cold"]["ms_per_step"] <= roof["cold"]["ms_per_step_with_kernel_events"]
+    if roof["traffic"]:
+        assert 0.1 < roof["bus_frac"] < 1.0
+    assert par["netflow_rel_err_at_fixed_v"] <= 1e-12 and par["route_native_netflow_rel_err"] <= 1e-6
+    assert par["route_converged_netflow_rel_err"] <= 1e-8
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "scaling"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-800:], r.stderr[-2000:])
+    assert r.returncode == 0
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    grid = line["grid"]
+    assert len(grid) == 30 and [g["m"] for g in grid[::3]] == [100, 167, 278, 464, 774, 1292, 2154, 3594, 5995, 10000]
+    assert (grid[0]["n_tokens"], grid[1]["n_tokens"], grid[2]["n_tokens"]) == (10, 20, 40)
+    for g in grid:
+        assert g["netflow_rel_err"] <= 1e-6 and g["native_evaluations"] >= 2 and 0 < g["native_ms"] < 50
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(line, open(os.path.join(ROOT, "gpurun_out", "bench_scaling_grid.json"), "w"), indent=1)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_route_across_processes_sharing_one_gpu(world):
     """A real multi-process run of the N > 1 path on the 1-GPU box: `world` processes (gloo rendezvous; RCCL
