@@ -330,7 +330,8 @@ def test_bench_self_spawns_one_rank_per_gpu(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0
-        assert "[rank 0/2] bench.py needs an MI355X" in out and "[rank 1/2] bench.py needs an MI355X" in out
+        # (torchrun tears the other rank down as soon as one has failed: at least one of them got to say why)
+        assert "[rank 0/2] bench.py needs an MI355X" in out or "[rank 1/2] bench.py needs an MI355X" in out
 
 
 def test_univ3_ticks_visited_bookkeeping_matches_the_oracle_walk():
