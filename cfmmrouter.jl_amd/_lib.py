@@ -41,6 +41,14 @@ class RouteInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class PolishInfo(C.Structure):
+    _fields_ = [("residual0", C.c_double), ("residual", C.c_double), ("iterations", C.c_int32), ("sweeps", C.c_int32),
+                ("total_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 FG_CALLBACK = C.CFUNCTYPE(C.c_double, C.c_void_p, _f64p, _f64p)
 
 
@@ -118,6 +126,7 @@ def lib():
     L.cfmm_kernel_times.argtypes = [_ctx, _i64p, _f64p, _i64p, _f64p]
     L.cfmm_route.argtypes = [_ctx, C.c_int32, _f64p, C.c_int32, _f64p, C.c_int32, C.c_double, C.c_double,
                              C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(RouteInfo)]
+    L.cfmm_polish.argtypes = [_ctx, C.c_int32, _f64p, C.c_int32, _f64p, C.c_int32, C.c_double, _f64p, C.POINTER(PolishInfo)]
     L.cfmm_lbfgsb_minimize.argtypes = [C.c_int32, _f64p, _f64p, _f64p, _i32p, FG_CALLBACK, C.c_void_p, C.c_int32,
                                        C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RouteInfo)]
     L.cfmm_set_peers.argtypes = [_ctx, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64]
@@ -312,6 +321,16 @@ class Context:
                                        int(m), float(factr), float(pgtol), int(maxfun), int(maxiter), ptr(v),
                                        ptr(psi), C.byref(info)))
         return v, psi, info.as_dict()
+
+    def polish(self, objective_kind, objective_vec, objective_index, v, max_iters=8, rel_step=1e-7):
+        """cfmm_polish: the gradient-only projected chord-Newton polish inside the library.  -> (v, psi, info dict)."""
+        ov = f64(objective_vec)
+        if ov.size != self.n_tokens:
+            raise ArgumentError("objective vector must have n_tokens entries")
+        vv, psi, info = f64(np.array(v, dtype=np.float64).copy()), np.empty(self.n_tokens), PolishInfo()
+        self._check(self._L.cfmm_polish(self._h, int(objective_kind), ptr(ov), int(objective_index), ptr(vv), int(max_iters),
+                                        float(rel_step), ptr(psi), C.byref(info)))
+        return vv, psi, info.as_dict()
 
     def update_reserves(self):
         """update_reserves!(r) on the device (cfmm_update_reserves): consumes the latest materialised trades."""

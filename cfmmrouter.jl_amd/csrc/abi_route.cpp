@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "lbfgsb.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -149,6 +150,139 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
         info->sweeps = sweeps;
         info->status = r.status;
         info->sweep_seconds = sweep_s;
+        info->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return CFMM_OK;
+}
+
+int cfmm_polish(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec, int32_t objective_index, double* v,
+                int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info)
+{
+    if (!c) return CFMM_ERR_INVALID_ARG;
+    const int n = c->n;
+    if (!objective_vec || !v) return fail(c, CFMM_ERR_INVALID_ARG, "objective vector / v is null");
+    if (objective_kind != CFMM_OBJ_LINEAR_NONNEGATIVE && objective_kind != CFMM_OBJ_BASKET_LIQUIDATION)
+        return fail(c, CFMM_ERR_INVALID_ARG, "unknown objective kind %d", objective_kind);
+    const bool linear = objective_kind == CFMM_OBJ_LINEAR_NONNEGATIVE;
+    if (!linear && (objective_index < 0 || objective_index >= n)) return fail(c, CFMM_ERR_INVALID_ARG, "Invalid index i");
+    if (!(rel_step > 0.0)) rel_step = 1e-7;
+    const auto t_begin = std::chrono::steady_clock::now();
+    armed_cancel(c);
+    // bounds and the objective's (constant) gradient: src/objectives.jl:69-79, :113-129
+    std::vector<double> lo(n), gobj(n, 0.0), x(n), G(n), xt(n), Gt(n), step(n);
+    const double sqrt_eps = std::sqrt(2.220446049250313e-16);
+    for (int j = 0; j < n; ++j) {
+        lo[j] = linear ? objective_vec[j] + 1e-8 : sqrt_eps;
+        if (!linear) gobj[j] = j == objective_index ? 0.0 : objective_vec[j];
+    }
+    if (!linear) lo[objective_index] = 1.0 + sqrt_eps;
+    for (int j = 0; j < n; ++j) x[j] = std::max(v[j], lo[j]);
+    int sweeps = 0;
+    auto gradient = [&](const std::vector<double>& at, std::vector<double>& out) {   // G = grad f + psi: one fused sweep
+        int rc = host_sweep(c, at.data(), false);
+        ++sweeps;
+        if (rc != CFMM_OK) return rc;
+        for (int j = 0; j < n; ++j) out[j] = gobj[j] + c->last_out[(size_t)j];
+        return (int)CFMM_OK;
+    };
+    std::vector<char> free_(n), freet(n);
+    auto residual = [&](const std::vector<double>& at, const std::vector<double>& g, std::vector<char>& fr) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) {
+            fr[j] = !(at[j] <= lo[j] && g[j] > 0.0);
+            if (fr[j]) r = std::max(r, std::fabs(g[j]));
+        }
+        return r;
+    };
+    int rc = gradient(x, G);
+    if (rc != CFMM_OK) return rc;
+    // forward-difference Jacobian (column j = dG / dv_j), row-major J[i*n + j]
+    std::vector<double> J((size_t)n * n);
+    xt = x;
+    for (int j = 0; j < n; ++j) {
+        xt[j] = x[j] * (1.0 + rel_step);
+        rc = gradient(xt, Gt);
+        if (rc != CFMM_OK) return rc;
+        const double h = xt[j] - x[j];
+        for (int i = 0; i < n; ++i) J[(size_t)i * n + j] = (Gt[i] - G[i]) / h;
+        xt[j] = x[j];
+    }
+    double res = residual(x, G, free_);
+    const double res0 = res;
+    int done = 0;
+    std::vector<int> idx;
+    std::vector<double> A, b;
+    for (int it = 0; it < max_iters && res > 0.0; ++it) {
+        idx.clear();
+        for (int j = 0; j < n; ++j)
+            if (free_[j]) idx.push_back(j);
+        const int nf = (int)idx.size();
+        A.assign((size_t)nf * nf, 0.0);
+        b.assign((size_t)nf, 0.0);
+        double amax = 0.0;
+        for (int a = 0; a < nf; ++a) {
+            for (int q = 0; q < nf; ++q) {
+                A[(size_t)a * nf + q] = J[(size_t)idx[a] * n + idx[q]];
+                amax = std::max(amax, std::fabs(A[(size_t)a * nf + q]));
+            }
+            b[a] = -G[idx[a]];
+        }
+        // Gaussian elimination with partial pivoting; a vanishing pivot (the dual is homogeneous of degree 0 in v: J v = 0,
+        // singular when no variable sits on a bound) is replaced by a tiny one -- the step is a search direction, the
+        // residual test below decides whether it is taken
+        const double tiny = 1e-13 * std::max(amax, 1e-300);
+        for (int k = 0; k < nf; ++k) {
+            int piv = k;
+            for (int r = k + 1; r < nf; ++r)
+                if (std::fabs(A[(size_t)r * nf + k]) > std::fabs(A[(size_t)piv * nf + k])) piv = r;
+            if (piv != k) {
+                for (int q = k; q < nf; ++q) std::swap(A[(size_t)k * nf + q], A[(size_t)piv * nf + q]);
+                std::swap(b[k], b[piv]);
+            }
+            double& d = A[(size_t)k * nf + k];
+            if (std::fabs(d) < tiny) d = d < 0 ? -tiny : tiny;
+            const double inv = 1.0 / d;
+            for (int r = k + 1; r < nf; ++r) {
+                const double f = A[(size_t)r * nf + k] * inv;
+                if (f == 0.0) continue;
+                double* ar = &A[(size_t)r * nf];
+                const double* ak = &A[(size_t)k * nf];
+                for (int q = k + 1; q < nf; ++q) ar[q] -= f * ak[q];
+                b[r] -= f * b[k];
+            }
+        }
+        for (int k = nf - 1; k >= 0; --k) {
+            double sum = b[k];
+            for (int q = k + 1; q < nf; ++q) sum -= A[(size_t)k * nf + q] * b[q];
+            b[k] = sum / A[(size_t)k * nf + k];
+        }
+        std::fill(step.begin(), step.end(), 0.0);
+        for (int a = 0; a < nf; ++a) step[idx[a]] = b[a];
+        bool improved = false;
+        for (double t = 1.0; t >= 1.0 / 64; t *= 0.5) {
+            for (int j = 0; j < n; ++j) xt[j] = std::max(x[j] + t * step[j], lo[j]);
+            rc = gradient(xt, Gt);
+            if (rc != CFMM_OK) return rc;
+            const double rt = residual(xt, Gt, freet);
+            if (rt < res) {
+                x = xt; G = Gt; free_ = freet; res = rt;
+                improved = true;
+                break;
+            }
+        }
+        ++done;
+        if (!improved) break;   // the rounding-noise floor of psi (or a kink the chord matrix cannot cross): keep the best iterate
+    }
+    rc = host_sweep(c, x.data(), true);   // find_arb!(r, v) at the polished point, as route! ends (src/router.jl:106-107)
+    ++sweeps;
+    if (rc != CFMM_OK) return rc;
+    std::copy(x.begin(), x.end(), v);
+    if (psi_out) std::memcpy(psi_out, c->last_out.data(), (size_t)n * sizeof(double));
+    if (info) {
+        info->residual0 = res0;
+        info->residual = res;
+        info->iterations = done;
+        info->sweeps = sweeps;
         info->total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
     return CFMM_OK;

@@ -332,7 +332,7 @@ def dual_jacobian(r: Router, v=None, rel_step=1e-7):
     return J
 
 
-def polish_(r: Router, iters=8, jacobian=None, rel_step=1e-7):
+def polish_(r: Router, iters=8, jacobian=None, rel_step=1e-7, native=None):
     """Tighten a route!'s result beyond what L-BFGS-B's stopping rules can: a projected chord-Newton iteration on the
     optimality conditions of the dual problem route! solves (src/router.jl:58-108),
 
@@ -350,7 +350,31 @@ def polish_(r: Router, iters=8, jacobian=None, rel_step=1e-7):
     (n_tokens + 1 sweeps).  Steps that do not reduce the residual are halved; the best iterate is kept.  Ends with
     find_arb!(r, ν) like route! does (:106-107), so r.v / r.Δs / r.Λs / netflows(r) describe the polished point.
     r.info["polish"] = {"residual0", "residual", "iterations", "sweeps"} (residual = max |G_F|, and −Gⱼ where a
-    variable on its bound has Gⱼ < 0)."""
+    variable on its bound has Gⱼ < 0).
+
+    native (default: True on an unsharded single-device router when no `jacobian` is given): the same iteration inside
+    the library (cfmm_polish, one C-ABI call: what a Julia or C caller uses)."""
+    if native is None:
+        native = jacobian is None and isinstance(r._backend, DeviceBackend) and getattr(r, "_guard", None) is None
+    if native:
+        if jacobian is not None or not isinstance(r._backend, DeviceBackend):
+            raise ArgumentError("native polish computes its own Jacobian on a DeviceBackend")
+        from ._lib import OBJ_BASKET_LIQUIDATION, OBJ_LINEAR_NONNEGATIVE
+        obj = r.objective
+        if isinstance(obj, _obj.LinearNonnegative):
+            kind, vec, idx = OBJ_LINEAR_NONNEGATIVE, obj.c, 0
+        else:
+            kind, vec, idx = OBJ_BASKET_LIQUIDATION, obj.Δin, obj.i - 1
+        vout, psi, pinfo = r._backend.ctx.polish(kind, vec, idx, r.v, max_iters=iters, rel_step=rel_step)
+        r.v[:] = vout
+        r._psi, r._acc = psi, r._backend.ctx.dual_value()
+        r._trades_stale = True
+        r.n_sweeps += pinfo["sweeps"]
+        info = dict(r.info) if isinstance(r.info, dict) else {}
+        info["polish"] = {k: pinfo[k] for k in ("residual0", "residual", "iterations", "sweeps")}
+        info["polish"]["native_seconds"] = pinfo["total_seconds"]
+        r.info = info
+        return None
     n = r.v.size
     lo = _obj.lower_limit(r.objective)
     sweeps0 = r.n_sweeps

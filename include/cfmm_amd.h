@@ -278,6 +278,27 @@ int cfmm_route(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_ve
                const double* v0, int32_t m, double factr, double pgtol, int32_t maxfun, int32_t maxiter,
                double* v_out, double* psi_out, cfmm_route_info* info);
 
+/* Tighten a route!'s result beyond what L-BFGS-B's stopping rules can (NOT part of the reference: its route! ends where
+ * LBFGSB.jl ends, src/router.jl:105-107).  L-BFGS-B's line search compares dual VALUES, whose rounding noise -- a sum
+ * over all pools -- hides decreases below ~1e-15 relative; on interior optima that leaves a stationarity residual of
+ * ~1e-6 max|psi|, on the reference's side as well.  cfmm_polish continues from v (in: a route!'s v*, out: the polished
+ * point) with a projected chord-Newton iteration on the optimality conditions of the dual problem of src/router.jl:58-108,
+ *     G_j(v) = 0 for l_j < v_j,   G_j(v) >= 0 for v_j = l_j,   G = grad f(objective, v) + psi(v),  l = lower_limit(objective),
+ * using GRADIENTS only: J = forward-difference Jacobian of G at the start (n_tokens + 1 fused sweeps, step rel_step * v_j;
+ * pass rel_step <= 0 for 1e-7), free set F = {j : not (v_j = l_j and G_j > 0)}, v_F <- max(l_F, v_F - J_FF^-1 G_F); steps that
+ * do not reduce the residual are halved, the best iterate is kept, at most max_iters iterations (8 is plenty).  Ends with
+ * find_arb!(r, v) like route! does: psi_out[n] = netflows(r), trades materialised at the polished point.  Objective
+ * arguments as for cfmm_route.  The Python mirror's polish_ (cfmmrouter.jl_amd/router.py) is the same iteration. */
+typedef struct cfmm_polish_info {
+    double residual0;    /* max |G_F| before (and -G_j where a variable on its bound has G_j < 0) */
+    double residual;     /* ... after */
+    int32_t iterations;
+    int32_t sweeps;      /* device sweeps of the call, Jacobian and final find_arb! included */
+    double total_seconds;
+} cfmm_polish_info;
+int cfmm_polish(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_vec, int32_t objective_index,
+                double* v, int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info);
+
 /* The solver alone on a caller-supplied objective (used by the CPU tests to compare it with
  * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g.
  * boxed_from_nbd != 0: like the Fortran code, treat the problem as "boxed" (unit first step) when

@@ -18,7 +18,7 @@ using CFMMRouter: CFMM, ProductTwoCoin, GeometricMeanTwoCoin, UniV3, Objective
 using LBFGSB
 import CFMMRouter: route!, netflows, netflows!, find_arb!, update_reserves!
 
-export AMDRouter, route_native!
+export AMDRouter, route_native!, polish!
 
 const LIB = get(ENV, "CFMM_AMD_LIB", "libcfmm_amd.so")
 
@@ -231,6 +231,41 @@ function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxf
         vout, r.Ψ, info))
     r.v .= vout
     # trades were materialised at v* by the same call
+    mm = length(r.cfmms)
+    D = Matrix{Float64}(undef, 2, mm); L = Matrix{Float64}(undef, 2, mm)
+    GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
+    for (k, i) in enumerate(r.order)
+        r.Δs[i] .= @view D[:, k]; r.Λs[i] .= @view L[:, k]
+    end
+    return info[]
+end
+
+# cfmm_polish (include/cfmm_amd.h): tighten a route!'s result with a gradient-only projected chord-Newton iteration on the
+# dual's optimality conditions -- NOT part of CFMMRouter.jl (its route! ends where L-BFGS-B ends, with a stationarity
+# residual of ~1e-6 max|Ψ| on interior optima); overwrites r.v, r.Δs, r.Λs like route! does.
+struct PolishInfo
+    residual0::Float64
+    residual::Float64
+    iterations::Int32
+    sweeps::Int32
+    total_seconds::Float64
+end
+
+function polish!(r::AMDRouter; max_iters=8, rel_step=1e-7)
+    obj = r.objective
+    kind, vec, idx = if obj isa CFMMRouter.LinearNonnegative
+        (Int32(0), Vector{Float64}(obj.c), Int32(0))
+    elseif obj isa CFMMRouter.BasketLiquidation
+        (Int32(1), Vector{Float64}(obj.Δin), Int32(obj.i - 1))
+    else
+        throw(ArgumentError("polish! knows LinearNonnegative and BasketLiquidation"))
+    end
+    vio = Vector{Float64}(r.v)
+    info = Ref(PolishInfo(0.0, 0.0, 0, 0, 0.0))
+    GC.@preserve vec vio check(r.ctx, ccall((:cfmm_polish, LIB), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ref{PolishInfo}),
+        r.ctx, kind, vec, idx, vio, max_iters, rel_step, r.Ψ, info))
+    r.v .= vio
     mm = length(r.cfmms)
     D = Matrix{Float64}(undef, 2, mm); L = Matrix{Float64}(undef, 2, mm)
     GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))

@@ -54,6 +54,14 @@ int main(void)
     printf("route: v=[%.12g, %.12g] psi=[%.12g, %.12g] evaluations=%d status=%d\n", vopt[0], vopt[1], psiopt[0],
            psiopt[1], info.evaluations, info.status);
 
+    /* cfmm_polish: the gradient-only polish from the route!'s v* (not part of the reference); a converged corner solution stays put */
+    double vpol[2] = {vopt[0], vopt[1]}, psipol[2];
+    cfmm_polish_info pinfo;
+    CHECK(cfmm_polish(ctx, CFMM_OBJ_LINEAR_NONNEGATIVE, c, 0, vpol, 8, 0.0, psipol, &pinfo));
+    printf("polish: psi=[%.12g, %.12g] residual %.3g -> %.3g in %d iterations, %d sweeps\n", psipol[0], psipol[1],
+           pinfo.residual0, pinfo.residual, pinfo.iterations, pinfo.sweeps);
+    if (!(fabs(psipol[1] - 171.4) < 0.1) || !(pinfo.residual <= pinfo.residual0 + 1e-9) || pinfo.sweeps < 4) return 6;
+
     /* error path: the reference's ArgumentError */
     const int32_t bad[2] = {0, 0};
     const double R1[2] = {1.0, 1.0}, g1[1] = {1.0};

@@ -583,6 +583,45 @@ def test_route_parity_by_convergence(name, solver):
         assert pol["residual"] <= 1e-9 * out["psi_scale"]
 
 
+@pytest.mark.parametrize("kind", ["basket", "arb"])
+def test_polish_inside_the_library_equals_the_python_mirror(kind):
+    """cfmm_polish (one C-ABI call: what a Julia or C caller uses) and router.py::polish_ are the same iteration: from the
+    same route! result both reach the same point (<= 1e-12 of max|Ψ|), with the optimality conditions satisfied to 1e-9
+    and r.Δs / r.Λs describing the polished point."""
+    n = 96
+    if kind == "basket":
+        market = [synth.bounded_product_pools(120_000, n, seed=91, consistent=True)]
+        obj, v0 = cr.BasketLiquidation(1, synth.basket(n, seed=91)), None
+    else:
+        market = [synth.product_pools(100_000, n, seed=92), synth.geomean_pools(50_000, n, seed=93)]
+        obj, v0 = cr.LinearNonnegative(synth.linear_prices(n, seed=92)), np.ones(n)
+    res = {}
+    for native in (True, False):
+        r = cr.Router(obj, market, n)
+        cr.route_(r, v=v0, solver="native")
+        before = cr.netflows(r).copy()
+        cr.polish_(r, native=native)
+        res[native] = (cr.netflows(r).copy(), r.v.copy(), dict(r.info["polish"]), r.Δs.copy(), r.Λs.copy(), before)
+        r.close()
+    (pn, vn, infn, Dn, Ln, before), (pp, vp, infp, _, _, _) = res[True], res[False]
+    scale = np.max(np.abs(pp))
+    assert rel_to_max(pn, pp) <= 1e-12 and np.max(np.abs(vn - vp) / vp) <= 1e-12
+    for inf in (infn, infp):
+        assert inf["residual"] <= 1e-9 * scale and inf["residual"] < inf["residual0"] and inf["sweeps"] <= n + 1 + 8 * 7 + 2
+    assert "native_seconds" in infn
+    assert rel_to_max(before, pn) <= 1e-5              # polish moved the route!'s result by its stopping slack only
+    Do, Lo, psi_o, _ = oracle_sweep(market, n, vn, nthreads=8)    # the trades left behind are those of a sweep at the polished prices
+    assert rel_to_max(pn, psi_o) <= 1e-12
+    np.testing.assert_allclose(Dn, Do, rtol=0, atol=1e-9 * np.max(Do))
+    np.testing.assert_allclose(Ln, Lo, rtol=0, atol=1e-9 * np.max(Lo))
+    lo = cr.lower_limit(obj)
+    G = np.zeros(n)
+    cr.grad_(G, obj, vn)
+    G += pn
+    on = vn <= lo
+    assert np.max(np.abs(G[~on])) <= 1e-9 * scale and np.all(G[on] >= -1e-9 * scale)
+
+
 @pytest.mark.parametrize("kind", ["arb", "basket", "mixed"])
 def test_route_native_solver_one_call(kind):
     """cfmm_route: the whole of route! inside the library (own L-BFGS-B) vs the CPU restatement."""

@@ -22,6 +22,7 @@ C2J = {   # C parameter type (const and spaces stripped) -> acceptable Julia cca
     "void*": {"Ptr{Cvoid}"},
     "void": {"Cvoid"},
     "cfmm_route_info*": {"Ref{RouteInfo}", "Ptr{RouteInfo}"},
+    "cfmm_polish_info*": {"Ref{PolishInfo}", "Ptr{PolishInfo}"},
 }
 
 
@@ -88,9 +89,13 @@ def test_every_ccall_matches_the_header():
             assert ja in C2J[ca], f"{name} argument {k}: Julia {ja} vs C {ca}"
 
 
-def test_route_info_struct_mirrors_the_header():
+import pytest
+
+
+@pytest.mark.parametrize("cname,jname", [("cfmm_route_info", "RouteInfo"), ("cfmm_polish_info", "PolishInfo")])
+def test_info_structs_mirror_the_header(cname, jname):
     h = open(os.path.join(ROOT, "include", "cfmm_amd.h")).read()
-    body = re.search(r"typedef struct[^{]*\{([^}]*)\}\s*cfmm_route_info", h, flags=re.S).group(1)
+    body = re.search(r"typedef struct[^{]*\{([^}]*)\}\s*" + cname, h, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
     cfields = []
     for decl in body.split(";"):
@@ -101,7 +106,7 @@ def test_route_info_struct_mirrors_the_header():
         for nm in names.split(","):
             cfields.append((nm.strip(), ty))
     j = open(os.path.join(ROOT, "julia", "CFMMRouterAMD.jl")).read()
-    jbody = re.search(r"struct RouteInfo\n(.*?)\nend", j, flags=re.S).group(1)
+    jbody = re.search(r"struct " + jname + r"\n(.*?)\nend", j, flags=re.S).group(1)
     jfields = [tuple(x.strip() for x in line.split("#")[0].split("::")) for line in jbody.splitlines() if "::" in line]
     tmap = {"double": "Float64", "int32_t": "Int32", "int64_t": "Int64", "int": "Int32"}
     assert [(n, tmap[t]) for n, t in cfields] == jfields
