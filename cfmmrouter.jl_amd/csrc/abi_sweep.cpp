@@ -494,12 +494,13 @@ bool prices_in_fast_window(const double* v, int n)
 }
 
 // Why did a sweep deliver NaN?  The blocks report through the sticky word (sweep.h kFlagWindow / kFlagGaveUp).
-unsigned long long take_flags(cfmm_ctx* c)
+// Returns the reported bits among `mask` and clears exactly those (a report nobody asked about stays for whoever does).
+unsigned long long take_flags(cfmm_ctx* c, unsigned long long mask)
 {
     if (!c->h_stage) return 0;
     volatile unsigned long long* w = reinterpret_cast<volatile unsigned long long*>(c->h_stage + c->flag_off);
-    const unsigned long long f = *w;
-    if (f) *w = 0;
+    const unsigned long long f = *w & mask;
+    if (f) *w = *w & ~f;
     return f;
 }
 
@@ -562,7 +563,7 @@ int take_host_out(cfmm_ctx* c)
         if (!std::isfinite(c->last_out[(size_t)j])) {
             c->have_out = false;
             (void)hipStreamSynchronize(c->stream);
-            const unsigned long long why = take_flags(c);
+            const unsigned long long why = take_flags(c, kFlagWindow);
             if (why & kFlagWindow) {   // (cannot happen on a host-pointer sweep: the host checked these prices)
                 c->dev_slow = true;
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}: a price lies outside the window of the fast arithmetic");
@@ -721,7 +722,7 @@ int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
     std::atomic_thread_fence(std::memory_order_acquire);
     if (!seen) {
         armed_lost(c, lost);
-        (void)take_flags(c);
+        (void)take_flags(c, kFlagGaveUp);
         return fail(c, CFMM_ERR_STATE, c->peers.empty()
                         ? "armed evaluation did not complete (the device never saw its price vector)"
                         : "armed evaluation did not complete within the arm + peer timeouts (this rank's launch never saw its "
@@ -732,7 +733,7 @@ int armed_wait(cfmm_ctx* c, uint64_t want, bool& lost)
     // timed out -- is reported by take_host_out as what it is.
     const double acc = c->h_stage[2 * c->n];
     if (acc != acc) {
-        const unsigned long long why = take_flags(c);
+        const unsigned long long why = take_flags(c, kFlagGaveUp);
         if (why & kFlagGaveUp) {
             armed_lost(c, lost);
             return fail(c, CFMM_ERR_STATE, "armed evaluation gave up waiting for its price vector (host stalled longer than the arm timeout)");
@@ -892,7 +893,7 @@ int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materializ
     // price outside [2^-150, 2^150] (or NaN / 0 / inf) does not compute -- it poisons {psi, acc} with NaN and reports it.
     // The next call finds the report and fails ONCE, saying so (nothing is enqueued); from then on this context's
     // device-pointer sweeps run the full-range kernels, which treat such prices like the reference's arithmetic does.
-    if (!c->dev_slow && (take_flags(c) & kFlagWindow)) {
+    if (!c->dev_slow && (take_flags(c, kFlagWindow) & kFlagWindow)) {
         c->dev_slow = true;
         return fail(c, CFMM_ERR_STATE, "an earlier device-pointer sweep met a price outside [2^-150, 2^150] and delivered NaN; "
                                        "device-pointer sweeps on this context use the full-range arithmetic from now on: repeat the call");

@@ -257,7 +257,7 @@ constexpr int kPricesUnknown = 0, kPricesInWindow = 1, kPricesOutside = 2;
 int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materialize, bool want_host_out = false,
                   uint64_t arm_seq = 0, int price_window = kPricesUnknown);
 bool prices_in_fast_window(const double* v, int n);
-unsigned long long take_flags(cfmm_ctx* c);
+unsigned long long take_flags(cfmm_ctx* c, unsigned long long mask);
 int check_prices(cfmm_ctx* c, const double* v);
 int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize);
 int host_sweep_end(cfmm_ctx* c);

@@ -570,7 +570,7 @@ struct UniV3Ops {
                     // the target price lies INSIDE this tick by more than a relative 2^-29: sqrt(k/price) is below its
                     // value at the tick's far boundary, s_in + δmax, by more than 2^-30 of it -- no later tick can be
                     // entered (its s_in is the square root at a boundary price beyond this one's; rounding is monotone)
-                    inside = dd < dmax - 0x1p-30 * (s_in + dmax);
+                    if (p.has_walk) inside = dd < dmax - 0x1p-30 * (s_in + dmax);   // (BoundedProduct segments have no lists: nothing to skip)
                 }
             }
         }
