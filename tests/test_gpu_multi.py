@@ -90,6 +90,24 @@ def test_config4_shape_eight_shards_route_parity():
         r1.close()
 
 
+def test_polish_on_a_multi_device_parent_equals_the_single_device_polish():
+    """cfmm_polish drives a multi-device parent like cfmm_route does (host-pointer sweeps over all shards): from the same
+    route! both reach the same converged point as one device."""
+    n = 64
+    market = [synth.bounded_product_pools(90_000, n, seed=41, consistent=True)]
+    obj = cr.BasketLiquidation(1, synth.basket(n, seed=41))
+    out = {}
+    for dev in (0, [0, 0, 0]):
+        r = cr.Router(obj, market, n, device=dev)
+        cr.route_(r, solver="native")
+        cr.polish_(r)                              # native: one C-ABI call
+        out[str(dev)] = (cr.netflows(r).copy(), r.v.copy(), dict(r.info["polish"]))
+        r.close()
+    (p1, v1, i1), (p3, v3, i3) = out["0"], out["[0, 0, 0]"]
+    assert rel_to_max(p3, p1) <= 1e-12 and np.max(np.abs(v3 - v1) / v1) <= 1e-12
+    assert i3["residual"] <= 1e-9 * np.max(np.abs(p1)) and "native_seconds" in i3
+
+
 def test_failed_upload_rolls_back_every_shard():
     """UniV3 batches are validated by the shards themselves: a bad pool in the LAST shard's block must
     undo the blocks the earlier shards already stored."""
