@@ -176,6 +176,7 @@ __device__ __forceinline__ void expand_dir(int dir, double d, double l, Trade& t
 
 struct ProductOps {
     static constexpr bool kNeedsLogPrices = false;
+    static constexpr bool kPrefetch = true;      // tile_loop: request the next tile's pool state before solving this one
     struct Raw {
         double2 R;
         double g;
@@ -292,6 +293,7 @@ __device__ __forceinline__ double geom_arb_lambda(double m, double r1, double r2
 
 struct GeoMeanOps {
     static constexpr bool kNeedsLogPrices = false;
+    static constexpr bool kPrefetch = true;
     struct Raw {
         double2 R, w;
         double g;
@@ -361,6 +363,7 @@ struct GeoMeanOps {
 // nothing here can overflow.
 struct GeoMeanLogOps {
     static constexpr bool kNeedsLogPrices = true;
+    static constexpr bool kPrefetch = true;
     struct Raw {
         double2 R, Q;
         double eta, g;
@@ -462,6 +465,7 @@ struct GeoMeanLogOps {
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
 struct UniV3Ops {
     static constexpr bool kNeedsLogPrices = false;
+    static constexpr bool kPrefetch = false;     // (measured +4 % on the multi-tick walk, +-0 on BoundedProduct segments)
     struct Raw {
         double2 pg, ca, cb;   // pg = {current_price, γ}
         double cc;
@@ -920,18 +924,34 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
 // the previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
 // 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
 // same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
-// (Requesting tile k+1 before tile k is solved was built and measured: +-0 warm, 2-3 % HBM-resident, at +8..16 VGPRs --
-// not kept, profiles/r03_ab_cold_geometry_prefetch_alternate.txt.)
+// Requesting tile k+1 before tile k is solved (Ops::kPrefetch): +-0 cache-warm, -2..-6 % HBM-resident on the two-coin
+// families at +6..8 VGPRs (round 3 measured the same and dropped it for the registers; since round 4's per-kernel
+// arithmetic they are free: profiles/r04_ab_prefetch_stores.txt); +4 % on the multi-tick UniV3 walk, which keeps the plain loop.
 template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FAST>
 __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, const SweepLds& L, typename Ops::Raw cur,
                                           int64_t i, int64_t step, int64_t left, double& acc)
 {
-    bool ok = left > 0;
-    while (ok) {
-        process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
-        i += step;
-        ok = --left > 0;
-        if (ok) cur = ops.template load<GBINS>(i);
+    if constexpr (Ops::kPrefetch) {
+        // tile k+1's pool state is requested before tile k is solved: two tiles' loads in flight per lane
+        bool ok = left > 0;
+        while (ok) {
+            const bool more = left > 1;
+            typename Ops::Raw nxt = cur;
+            if (more) nxt = ops.template load<GBINS>(i + step);
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
+            i += step;
+            --left;
+            ok = more;
+            cur = nxt;
+        }
+    } else {
+        bool ok = left > 0;
+        while (ok) {
+            process_pool<Ops, MAT, GBINS, FAST>(ops, a, L, cur, i, acc);
+            i += step;
+            ok = --left > 0;
+            if (ok) cur = ops.template load<GBINS>(i);
+        }
     }
 }
 
