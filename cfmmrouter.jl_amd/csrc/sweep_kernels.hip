@@ -924,14 +924,14 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
 // the previous one touched last -- the part that is still in the XCD's 4 MB L2 (a forward-only walk over a
 // 5.5 MB-per-XCD working set is the LRU worst case: 0 % hits; measured on a plain read stream of the
 // same 44 MB: 9.6 -> 6.9 us, profiles/r02_launch_floor.txt).
-// Requesting tile k+1 before tile k is solved (Ops::kPrefetch): +-0 cache-warm, -2..-6 % HBM-resident on the two-coin
-// families at +6..8 VGPRs (round 3 measured the same and dropped it for the registers; since round 4's per-kernel
+// Requesting tile k+1 before tile k is solved (Ops::kPrefetch, single-family launches): +-0.1 us cache-warm, -4..-6 %
+// HBM-resident on the two-coin families at +6..8 VGPRs (round 3 measured the same and dropped it for the registers; since round 4's per-kernel
 // arithmetic they are free: profiles/r04_ab_prefetch_stores.txt); +4 % on the multi-tick UniV3 walk, which keeps the plain loop.
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FAST>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FAST, bool PREFETCH>
 __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, const SweepLds& L, typename Ops::Raw cur,
                                           int64_t i, int64_t step, int64_t left, double& acc)
 {
-    if constexpr (Ops::kPrefetch) {
+    if constexpr (PREFETCH) {
         // tile k+1's pool state is requested before tile k is solved: two tiles' loads in flight per lane
         bool ok = left > 0;
         while (ok) {
@@ -964,7 +964,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
 // prices it stages; outside the window it does NOT compute: it poisons its row (NaN in every column -- an error, never
 // a wrong number) and reports kFlagWindow, upon which the library switches the context's device-pointer sweeps to the
 // full-range kernels (abi_sweep.cpp).
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK, bool MULTI>
 __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
                                               bool& poison)
 {
@@ -985,7 +985,9 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
         report(a, kFlagWindow);
     }
     if (poison) left = 0;
-    tile_loop<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, L, cur, i, step, left, acc);
+    // next-tile prefetch: single-family launches of the two-coin families (HBM-resident -4..-6 %, cache-warm +-0.1 us); the
+    // fused multi-family launch keeps the plain loop (same-box A/B on config3: -2 % HBM-resident but +1.5 % on the warm step)
+    tile_loop<Ops, MAT, BLOCK, GBINS, FASTK, Ops::kPrefetch && !MULTI>(ops, a, L, cur, i, step, left, acc);
     return acc;
 }
 
@@ -1020,19 +1022,19 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
 
 // One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
 // row goes to partials[row_id].
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK, bool MULTI>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
     bool poison;
-    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, L, bid, nblocks, poison);
+    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS, FASTK, MULTI>(ops, a, L, bid, nblocks, poison);
     finish_row<BLOCK, GBINS>(a, L, acc, row_id, poison);
 }
 
 template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
-    sweep_body<Ops, MAT, BLOCK, GBINS, FASTK>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
+    sweep_body<Ops, MAT, BLOCK, GBINS, FASTK, false>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Several segments (pool families) in ONE launch, so HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean /
@@ -1071,13 +1073,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
     a.gflow = sg.gflow;
     switch (sg.kind) {
     case 0:
-        sweep_body<ProductOps, MAT, BLOCK, GBINS, FASTK>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
+        sweep_body<ProductOps, MAT, BLOCK, GBINS, FASTK, true>(ProductOps{sg.pools.p}, a, local, nblocks, bidx);
         break;
     case 1: // log-space forms only; geomean_exact routers are swept by per-segment launches
-        sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS, FASTK>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
+        sweep_body<GeoMeanLogOps, MAT, BLOCK, GBINS, FASTK, true>(GeoMeanLogOps{sg.pools.g}, a, local, nblocks, bidx);
         break;
     default:
-        sweep_body<UniV3Ops, MAT, BLOCK, GBINS, FASTK>(UniV3Ops{sg.pools.u}, a, local, nblocks, bidx);
+        sweep_body<UniV3Ops, MAT, BLOCK, GBINS, FASTK, true>(UniV3Ops{sg.pools.u}, a, local, nblocks, bidx);
         break;
     }
 }
