@@ -288,7 +288,9 @@ int cfmm_route(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_ve
  * pass rel_step <= 0 for 1e-7), free set F = {j : not (v_j = l_j and G_j > 0)}, v_F <- max(l_F, v_F - J_FF^-1 G_F); steps that
  * do not reduce the residual are halved, the best iterate is kept, at most max_iters iterations (8 is plenty).  Ends with
  * find_arb!(r, v) like route! does: psi_out[n] = netflows(r), trades materialised at the polished point.  Objective
- * arguments as for cfmm_route.  The Python mirror's polish_ (cfmmrouter.jl_amd/router.py) is the same iteration. */
+ * arguments as for cfmm_route.  The Python mirror's polish_ (cfmmrouter.jl_amd/router.py) is the same iteration.  Works on
+ * multi-device contexts; on a cfmm_set_peers context every rank must make the same call (its sweeps are collective, and
+ * all ranks see bit-identical psi, hence take identical steps). */
 typedef struct cfmm_polish_info {
     double residual0;    /* max |G_F| before (and -G_j where a variable on its bound has G_j < 0) */
     double residual;     /* ... after */
