@@ -1,0 +1,209 @@
+"""The outer loop of route! pinned to the solver the reference calls: FORTRAN L-BFGS-B 3.0 (src/router.jl:60,105 ->
+LBFGSB.jl -> setulb).  tests/golden/route_fortran.npz holds runs of that Fortran code (SciPy 1.7.1's F2PY wrap of
+lbfgsb.f, driven through `_lbfgsb.setulb` with the reference's exact call shape: nbd = 2 everywhere, u = Inf, m = 5,
+factr = 1e1, pgtol = 1e-5) on the CPU restatement of fn / g!; tests/golden/make_route_golden.py made it and says how.
+
+CPU (this file, not gpu): csrc/lbfgsb.cpp on the SAME callbacks reproduces the Fortran run -- every evaluation point of
+the first 20 evaluations to rounding, the evaluation count exactly on the arbitrage markets, Ψ* within north_star's 1e-6
+everywhere -- and the fixture regenerates bit for bit where the Fortran build is present.
+GPU: the same solver driven by DEVICE sweeps follows the Fortran-on-restatement trajectory, and cfmm_route's netflows
+are held against the fixture's Ψ* with the fixture's OWN reorder slack beside them (`*_slack`: the same Fortran solver on
+the same market with its pools in another order -- the reference sums in pool order, src/router.jl:81-83 -- ends that far
+from itself).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cfmmrouter_amd as cr
+from cfmmrouter_amd import synth
+from helpers import OracleBackend, rel_to_max
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "route_fortran.npz")
+FORTRAN_PY = "/opt/conda/bin/python3.9"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def mini_market(name):
+    if name == "readme":
+        b = cr.ProductTwoCoin.batch([[1e6, 1e6], [1e3, 2e3]], [1.0, 1.0], [[1, 2], [1, 2]])
+        return [b], 2, cr.LinearNonnegative(np.ones(2)), None
+    if name == "config2_mini":
+        n = 64
+        return [synth.product_pools(20_000, n, seed=1234)], n, cr.LinearNonnegative(synth.linear_prices(n, seed=1234)), np.ones(n)
+    if name == "config3_mini":
+        n = 128
+        return ([synth.product_pools(20_000, n, seed=1234), synth.geomean_pools(20_000, n, seed=1234)], n,
+                cr.LinearNonnegative(synth.linear_prices(n, seed=1234)), np.ones(n))
+    if name == "config4_mini":
+        n = 512
+        return [synth.product_pools(50_000, n, seed=1234)], n, cr.LinearNonnegative(synth.linear_prices(n, seed=1234)), np.ones(n)
+    if name == "config5_300k":
+        n = 256
+        return ([synth.bounded_product_pools(300_000, n, seed=1234, consistent=True)], n,
+                cr.BasketLiquidation(1, synth.basket(n, seed=1234)), None)
+    if name == "univ3_mini":
+        n = 128
+        return [synth.univ3_ragged_pools(30_000, n, seed=1234)], n, cr.BasketLiquidation(1, synth.basket(n, seed=1234)), None
+    raise KeyError(name)
+
+
+class PassThrough:
+    """Any backend behind a type the Router does not know: route_(solver="native") then drives csrc/lbfgsb.cpp from
+    Python, one callback per evaluation (the path sharded and test-injected backends take), which can be logged."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def eval(self, v):
+        return self.inner.eval(v)
+
+    def find_arb(self, v):
+        return self.inner.find_arb(v)
+
+    def trades(self, out=None):
+        return self.inner.trades() if out is None else self.inner.trades(out)
+
+
+def trajectory_gap(xs, ref):
+    k = min(len(xs), len(ref))
+    return np.array([np.max(np.abs(xs[i] - ref[i]) / np.abs(ref[i])) for i in range(k)])
+
+
+def native_route_logged(obj, market, n, v0, backend):
+    """route! with csrc/lbfgsb.cpp (the reference's call shape) over `backend`; every point the solver asks fn / g! at is
+    logged -- like the fixture's xs, which log the Fortran code's FG requests (repeated requests at one point included)."""
+    import cfmmrouter_amd._lib as L
+    xs, orig = [], L.lbfgsb_minimize
+
+    def logged(fun, x0, bounds, **kw):
+        def fun2(x):
+            xs.append(np.array(x, dtype=np.float64))
+            return fun(x)
+        return orig(fun2, x0, bounds, **kw)
+
+    r = cr.Router(obj, market, n, _backend=PassThrough(backend))
+    L.lbfgsb_minimize = logged
+    try:
+        cr.route_(r, v=v0, solver="native")
+    finally:
+        L.lbfgsb_minimize = orig
+    assert len(xs) == r.info["funcalls"]
+    return r, xs
+
+
+# ---- CPU: the library's solver against the Fortran runs, same callbacks --------------------------------------------
+
+ARBITRAGE = ("readme", "config2_mini", "config3_mini", "config4_mini")
+INTERIOR = ("config5_300k", "univ3_mini")
+
+
+def test_fixture_is_the_fortran_lineage(gold):
+    assert str(gold["scipy_version"]) == "1.7.1"        # the last SciPy line that F2PY-wraps lbfgsb.f 3.0 itself
+    for name in ARBITRAGE + INTERIOR + ("full_config3", "full_config5"):
+        assert int(gold[name + "_evaluations"]) == len(gold[name + "_fs"])
+        assert gold[name + "_xs"].shape[1] == gold[name + "_v"].size
+
+
+@pytest.mark.parametrize("name", ARBITRAGE + INTERIOR)
+def test_native_solver_reproduces_the_fortran_run(gold, name):
+    market, n, obj, v0 = mini_market(name)
+    r, xs = native_route_logged(obj, market, n, v0, OracleBackend(n, market, nthreads=4))
+    ref_xs = gold[name + "_xs"]
+    dx = trajectory_gap(xs, ref_xs)
+    # every evaluation point of the first 20 evaluations (all of them on shorter runs): Cauchy point, subspace step, the
+    # boxed unit first step, every More'-Thuente trial -- the same DECISIONS as the Fortran code, to rounding
+    assert np.all(dx[:20] <= 1e-11), dx[:20]
+    psi_gap = rel_to_max(cr.netflows(r), gold[name + "_psi"])
+    evals, evals_f = r.info["funcalls"], int(gold[name + "_evaluations"])
+    if name in ARBITRAGE:
+        # corner optima: the two codes stay together to the end -- same number of evaluations, same netflows
+        assert evals == evals_f
+        assert np.all(dx <= 1e-11)
+        assert psi_gap <= 1e-12
+        assert abs(r.info["f"] - float(gold[name + "_f"])) <= 1e-14 * abs(float(gold[name + "_f"]))
+    else:
+        # interior optima: rounding differences grow with the conditioning after ~30 evaluations; both stop on factr inside
+        # the rounding noise of the dual value.  north_star's bar, against the Fortran run:
+        assert psi_gap <= 1e-6, psi_gap
+        assert abs(r.info["f"] - float(gold[name + "_f"])) <= 1e-13 * abs(float(gold[name + "_f"]))
+        assert 0.6 * evals_f <= evals <= 1.6 * evals_f
+    print(f"{name}: evaluations {evals} (Fortran {evals_f}), max dx first 20 {dx[:20].max():.1e}, overall {dx.max():.1e}, "
+          f"netflows vs Fortran {psi_gap:.1e}, Fortran reorder slack {float(gold[name + '_slack']):.1e}")
+
+
+def test_the_reference_solver_is_not_reproducible_to_1e6_under_pool_reordering(gold):
+    """What "the reference's netflows" are defined to: the Fortran solver on the same BASELINE-size markets with the pools
+    in another order (only the rounding of the pool-order sums changes) ends this far from itself.  On the interior optima
+    of config 5 that is ABOVE north_star's 1e-6 -- no implementation can be within 1e-6 of all of these runs at once."""
+    slack = {k[5:-6]: float(gold[k]) for k in gold.files if k.startswith("full_") and k.endswith("_slack")}
+    assert set(slack) == {"config2", "config3", "config4shard", "config5", "product1m", "univ3_ticks"}
+    assert slack["config3"] <= 1e-7 and slack["config2"] <= 1e-6 and slack["product1m"] <= 1e-6
+    assert slack["config5"] > 1e-6 and slack["univ3_ticks"] > 1e-6
+    evals = {k[5:-17]: gold[k] for k in gold.files if k.startswith("full_") and k.endswith("_perm_evaluations")}
+    assert np.ptp(np.append(evals["config5"], int(gold["full_config5_evaluations"]))) >= 20   # 124 .. 176 evaluations
+
+
+@pytest.mark.skipif(not os.path.exists(FORTRAN_PY), reason="no /opt/conda Python 3.9 + SciPy 1.7.1 (Fortran L-BFGS-B) here")
+def test_fixture_regenerates_bit_for_bit(gold, tmp_path):
+    out = tmp_path / "again.npz"
+    env = dict(os.environ, PYTHONWARNINGS="ignore")
+    p = subprocess.run([FORTRAN_PY, os.path.join(HERE, "golden", "make_route_golden.py"), "--only",
+                        "readme,config3_mini,univ3_mini", "--out", str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    again = np.load(out)
+    for name in ("readme", "config3_mini", "univ3_mini"):
+        for k in ("xs", "v", "psi", "fs", "perm_psi"):
+            np.testing.assert_array_equal(again[f"{name}_{k}"], gold[f"{name}_{k}"])
+        assert int(again[name + "_evaluations"]) == int(gold[name + "_evaluations"])
+
+
+# ---- GPU: the device route! against the Fortran runs at BASELINE size ----------------------------------------------
+
+FULL = ("config2", "config3", "config4shard", "config5", "product1m", "univ3_ticks")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FULL)
+def test_device_route_against_the_fortran_run(gold, name):
+    sys.path.insert(0, os.path.dirname(HERE))
+    from benchlib.workloads import WORKLOADS, build_market, objective_for
+    n = WORKLOADS[name][1]
+    market, obj = build_market(name, 0, 1, "weak"), objective_for(name, n)
+    v0 = np.ones(n) if isinstance(obj, cr.LinearNonnegative) else None
+    key = "full_" + name
+    psi_f, slack = gold[key + "_psi"], float(gold[key + "_slack"])
+    # (1) the kernel isolated from the solver: the device sweep at the FORTRAN run's v* returns its netflows
+    r = cr.Router(obj, market, n)
+    try:
+        cr.find_arb_(r, gold[key + "_v"])
+        assert rel_to_max(cr.netflows(r), psi_f) <= 1e-12
+        # (2) cfmm_route (one C-ABI call, pre-armed evaluations) at the reference's tolerances
+        cr.route_(r, v=v0, solver="native")
+        gap, evals = rel_to_max(cr.netflows(r), psi_f), r.info["funcalls"]
+    finally:
+        r.close()
+    # (3) the same solver driven by device sweeps through a logging backend: the Fortran trajectory, to rounding
+    be = cr.DeviceBackend(n, market)
+    try:
+        r2, xs = native_route_logged(obj, market, n, v0, be)
+        dx = trajectory_gap(xs, gold[key + "_xs"])
+        gap2 = rel_to_max(cr.netflows(r2), psi_f)
+    finally:
+        be.close()
+    print(f"{name}: cfmm_route vs Fortran {gap:.2e} ({evals} evaluations, Fortran {int(gold[key + '_evaluations'])}, "
+          f"reordered Fortran runs {gold[key + '_perm_evaluations'].tolist()}), callback-driven {gap2:.2e}; Fortran reorder slack "
+          f"{slack:.2e}; trajectory gap first 20 evaluations {dx[:20].max():.1e}")
+    assert np.all(dx[:min(20, len(dx))] <= 1e-9), dx[:20]
+    # north_star's 1e-6 where the reference itself is defined that well; elsewhere no further from the Fortran run than
+    # the Fortran run is from itself under a reordering of the pools (3 reorderings sampled: a factor for the sampling)
+    assert gap <= max(1e-6, 3.0 * slack), (gap, slack)
+    assert gap2 <= max(1e-6, 3.0 * slack), (gap2, slack)
