@@ -38,6 +38,10 @@ sys.path.insert(0, ROOT)
 # kernel arguments in device memory: measured 22.2 vs 24.9 us per step (config3) and 7.0 vs 9.1 (config2)
 # against HIP_FORCE_DEV_KERNARG=0; it is the ROCm 7 default on this box, pinned here in case it is not
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# the CPU restatement's OpenMP threads (cpu_baseline leg only): one per core, spread over the sockets, pinned -- round to
+# round the unpinned figure moved by 1.4x (1.35e7 .. 2.39e7 pools/s over rounds 1-4)
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 import numpy as np
 import torch
@@ -64,20 +68,45 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
     ps = oracle_poolset(batches, n)
     threads = orc.lib().oracle_max_threads()
     if "TORCHELASTIC_RUN_ID" in os.environ:   # torchrun exports OMP_NUM_THREADS=1; rank 0 is the only rank doing host work here
-        threads = max(threads, min(128, max(1, len(os.sched_getaffinity(0)) // 2)))   # one per physical core (SMT siblings only add contention to this memory-bound loop: measured 4e6 pools/s on 256 threads vs 2.3e7 on 128)
+        threads = max(1, min(128, max(1, len(os.sched_getaffinity(0)) // 2)))   # one per physical core (SMT siblings only add contention to this memory-bound loop: measured 4e6 pools/s on 256 threads vs 2.3e7 on 128)
     m = ps.m
-    reps, t_tot = 0, 0.0
-    ps.sweep(v, threads)  # warm caches / thread pool
-    while t_tot < budget_s and reps < 200:
+    # find_arb!(r, v) overwrites r.Δs / r.Λs in place (src/router.jl:40): the outputs are allocated ONCE, like the
+    # reference's; the threaded sweep (Threads.@threads, :39) and the two SERIAL reductions of fn / g! (:81-83, :98-100) are
+    # timed separately -- at 128 threads the serial part is most of a CPU evaluation (Amdahl), which is what the GPU path's
+    # in-kernel reductions remove.  Thread placement: OMP_PLACES=cores / OMP_PROC_BIND=spread (set at the top of this file).
+    D, L = np.empty((m, 2)), np.empty((m, 2))
+    G = np.zeros(n)
+    ps.sweep_into(v, D, L, threads)  # warm caches / thread pool
+    reps, t_sweep, t_red, per_rep = 0, 0.0, 0.0, []
+    while t_sweep + t_red < budget_s and reps < 400:
         t0 = time.perf_counter()
-        D, L = ps.sweep(v, threads)
+        ps.sweep_into(v, D, L, threads)
+        t1 = time.perf_counter()
         acco = orc.dual_acc(D, L, ps.Ai, v)
-        G = np.zeros(n)
+        G[:] = 0.0
         orc.grad_scatter(G, D, L, ps.Ai)
-        t_tot += time.perf_counter() - t0
+        t2 = time.perf_counter()
+        t_sweep += t1 - t0
+        t_red += t2 - t1
+        per_rep.append(t2 - t0)
         reps += 1
-    base = {"value": m * reps / t_tot, "unit": "pools/s", "cores": int(threads), "kind": "port",
-            "sample": f"{reps} full sweeps of the same {m}-pool workload (oracle/cfmm_oracle.c: OpenMP sweep + "
+    t_tot = t_sweep + t_red
+    one = []
+    for _ in range(2):                   # the same sweep on ONE thread (bounded: two sweeps)
+        t0 = time.perf_counter()
+        ps.sweep_into(v, D, L, 1)
+        one.append(time.perf_counter() - t0)
+    ps.sweep_into(v, D, L, threads)
+    per_rep = np.sort(np.array(per_rep))
+    base = {"value": m * reps / t_tot, "unit": "pools/s", "cores": int(threads), "threads": int(threads), "kind": "port",
+            "sweep_ms": 1e3 * t_sweep / reps, "reductions_ms": 1e3 * t_red / reps,
+            "value_sweep_only": m * reps / t_sweep, "value_1thread": m / (min(one) + t_red / reps),
+            "sweep_1thread_ms": 1e3 * min(one),
+            "evaluation_ms_quartiles": [float(1e3 * per_rep[int(q * (len(per_rep) - 1))]) for q in (0.25, 0.5, 0.75)],
+            "is": "value = pools / (threaded sweep + the reference's two serial reductions); sweep_ms is the Threads.@threads part "
+                  "(src/router.jl:39), reductions_ms the single-threaded loops of fn / g! (:81-83, :98-100); value_1thread = the "
+                  "same evaluation on one thread; outputs pre-allocated, OMP_PLACES=cores OMP_PROC_BIND=spread",
+            "sample": f"{reps} full evaluations of the same {m}-pool workload (oracle/cfmm_oracle.c: OpenMP sweep + "
                       f"serial dual/gradient reductions), {t_tot:.1f} s of host time; the Julia reference itself "
                       f"cannot run here (no Julia toolchain)"}
     parity = {"netflow_rel_err_at_fixed_v": float(np.max(np.abs(psi_dev[:n] - G)) / np.max(np.abs(G))),
@@ -93,6 +122,7 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
         scale = np.max(np.abs(ref["psi"]))
         for key, psi in legs.items():
             parity["route" + key[len("_psi"):] + "_netflow_rel_err"] = float(np.max(np.abs(psi - ref["psi"])) / scale)
+        parity.update(fortran_parity(name, legs, m))
         # the KERNEL isolated from the solver: the HIP sweep at the oracle's v* against the oracle's Ψ* (callback given by
         # the caller: it owns the device contexts), and how far the two solvers' v* are apart
         at = route_gpu.get("_sweep_at")
@@ -123,6 +153,120 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
     return base, parity
 
 
+
+
+def fortran_parity(name, legs, m):
+    """Route-level parity against the solver the reference CALLS: tests/golden/route_fortran.npz holds runs of the Fortran
+    L-BFGS-B 3.0 `setulb` (the code behind LBFGSB.jl, src/router.jl:60,105) with the reference's call shape on the CPU
+    restatement of this very market (tests/golden/make_route_golden.py).  `fortran_reorder_slack` = how far that Fortran run
+    ends from ITSELF when the market's pools are listed in another order (the reference sums in pool order): what the
+    reference's netflows are defined to at its own tolerances."""
+    path = os.path.join(ROOT, "tests", "golden", "route_fortran.npz")
+    key = "full_" + name
+    try:
+        g = np.load(path)
+        if key + "_psi" not in g.files or int(np.sum(g[key + "_v"].size)) == 0:
+            return {}
+        psi_f = g[key + "_psi"]
+        out = {"fortran_reorder_slack": float(g[key + "_slack"]), "fortran_evaluations": int(g[key + "_evaluations"]),
+               "fortran_reordered_evaluations": [int(x) for x in g[key + "_perm_evaluations"]],
+               "fortran_is": "Fortran L-BFGS-B 3.0 setulb (SciPy 1.7.1 F2PY wrap, reference call shape nbd=2 / u=Inf / m=5 / "
+                             "factr=1e1 / pgtol=1e-5) on the CPU restatement of this market: tests/golden/route_fortran.npz"}
+        for k, psi in legs.items():
+            if psi is not None and psi.shape == psi_f.shape:
+                out["route" + k[len("_psi"):] + "_vs_fortran_netflow_rel_err"] = float(np.max(np.abs(psi - psi_f)) / np.max(np.abs(psi_f)))
+        return out
+    except Exception as e:
+        return {"fortran_parity_error": repr(e)[:200]}
+
+
+def other_configs(args, local_rank, budget_s):
+    """Every other BASELINE configuration (+ product1m and the multi-tick UniV3 workload) in the SAME default run, so the
+    driver's line shows all of them: per workload a short timed pass (K = 20, W = 5: ms/step, pools/s),
+    the kernel-event pass (warm kernel time), the HBM-resident pass over a ring sized by touched bytes (kernel time, frac,
+    bus_frac from the committed PMC bytes of that workload), fixed-v parity against the CPU restatement (ONE oracle sweep: this
+    function is part of the CPU leg) and the library's route! against the Fortran L-BFGS-B fixture.  A few seconds each;
+    bounded by `budget_s` (workloads that no longer fit are listed under `skipped`)."""
+    from oracle import cfmm_oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_poolset
+    from benchlib.workloads import HBM_PEAK_GBS, alg_bytes
+    out, t_start = {}, time.perf_counter()
+    try:
+        committed = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        committed = {}
+    sub = argparse.Namespace(**vars(args))
+    sub.steps, sub.warmup = 20, 5
+    for name in ("config2", "config4shard", "config5", "product1m", "univ3_ticks"):
+        if time.perf_counter() - t_start > budget_s:
+            out.setdefault("skipped", []).append(name)
+            continue
+        t0 = time.perf_counter()
+        try:
+            sb = ShardBench(sub, name, "weak", 0, 1, local_rank, False)
+            for _ in range(sub.warmup):
+                sb.step()
+            elapsed, _ = sb.timed_pass(sub.steps)
+            kt, _ = sb.kernel_pass(sub.steps)
+            psi = sb.out_t.cpu().numpy().copy()
+            cold = sb.cold_pass(sub.steps)
+            ab = alg_bytes(sb.batches, sb.materialize, sb.v)
+            warm_ms = kt["sweep_ms"] / sub.steps
+            tr = committed.get(name)
+            rec = {"workload": WORKLOADS[name][0], "pools": sb.m_rank, "n_tokens": sb.n,
+                   "ms_per_step": 1e3 * elapsed / sub.steps, "value": sb.m_rank * sub.steps / elapsed,
+                   "ms_per_step_hbm_resident": cold["ms_per_step"], "value_hbm_resident": sb.m_rank / (cold["ms_per_step"] * 1e-3),
+                   "kernel_ms_warm": warm_ms, "kernel_ms_hbm_resident": cold["kernel_ms"], "reduce_kernel_ms": kt["reduce_ms"] / sub.steps,
+                   "alg_bytes_per_launch": ab, "frac": cold["frac"], "frac_warm": ab / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "traffic": tr, "bus_frac": (tr / (cold["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                   "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes of this workload)" if tr else None,
+                   "step_frac": ab / (1e3 * elapsed / sub.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "ring": {k: cold[k] for k in ("copies", "touched_per_copy", "bytes_touched", "hbm_resident")}}
+            # parity at fixed v: the timed path's {Ψ, acc} against ONE sweep of the CPU restatement
+            ps = oracle_poolset(sb.batches, sb.n)
+            D, L = np.empty((ps.m, 2)), np.empty((ps.m, 2))
+            ps.sweep_into(sb.v, D, L, orc.lib().oracle_max_threads())
+            G = np.zeros(sb.n)
+            orc.grad_scatter(G, D, L, ps.Ai)
+            acco = orc.dual_acc(D, L, ps.Ai, sb.v)
+            rec["parity"] = {"netflow_rel_err_at_fixed_v": float(np.max(np.abs(psi[:sb.n] - G)) / np.max(np.abs(G))),
+                             "dual_rel_err": float(abs(psi[sb.n] - acco) / max(abs(acco), 1.0))}
+            # route! (cfmm_route, one call) against the Fortran fixture of this market
+            obj = objective_for(name, sb.n)
+            v0 = np.ones(sb.n) if isinstance(obj, cr.LinearNonnegative) else None
+            r = cr.Router(obj, sb.batches, sb.n, device=local_rank)
+            try:
+                cr.route_(r, v=v0, solver="native")
+                ts = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    cr.route_(r, v=v0, solver="native")
+                    ts.append(time.perf_counter() - t1)
+                rec["route_ms"] = 1e3 * min(ts)
+                rec["route_evaluations"] = r.info.get("funcalls")
+                rec["parity"].update(fortran_parity(name, {"_psi_native": cr.netflows(r).copy()}, sb.m_rank))
+            finally:
+                r.close()
+            sb.close()
+            rec["seconds"] = time.perf_counter() - t0
+            out[name] = rec
+        except Exception as e:      # informational block: never lose the bench line over it
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
+def summary_string(rec):
+    """<= 120 characters: what a parser that keeps only scalars of `config` still shows of a workload"""
+    if "error" in rec:
+        return ("error: " + rec["error"])[:120]
+    p = rec.get("parity", {})
+    return ("step %.1fus hbm %.1fus | kern %.2f/%.2fus | frac %.2f bus %s | fixv %.0e fortran %s slack %s"
+            % (1e3 * rec["ms_per_step"], 1e3 * rec["ms_per_step_hbm_resident"], 1e3 * rec["kernel_ms_warm"],
+               1e3 * rec["kernel_ms_hbm_resident"], rec["frac"], ("%.2f" % rec["bus_frac"]) if rec.get("bus_frac") else "-",
+               p.get("netflow_rel_err_at_fixed_v", float("nan")),
+               ("%.0e" % p["route_native_vs_fortran_netflow_rel_err"]) if "route_native_vs_fortran_netflow_rel_err" in p else "-",
+               ("%.0e" % p["fortran_reorder_slack"]) if "fortran_reorder_slack" in p else "-"))[:120]
 
 
 def scaling_grid_main(args):
@@ -179,6 +323,9 @@ def main():
     ap.add_argument("--fused", action="store_true", help="time the fused evaluation (no Δ/Λ write-back)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-cold pass")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default workload at N = 1: skip the `configs` block (the other BASELINE configurations in the same run)")
+    ap.add_argument("--configs-budget-s", type=float, default=150.0, help="time budget of the `configs` block")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 PMC passes of this command (two bounded child runs); "
                          "use the committed profiles/traffic.json")
@@ -301,6 +448,15 @@ def main():
         "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "fast_math", "armed",
                                                                "stop_in_noise", "host_flag", "zero_copy")},
     }
+    if cold is not None:
+        # the HBM-resident step beside `value` (which is the cache-warm step: the same market every step, as inside route!)
+        line["value_hbm_resident"] = world * sb.m_rank / (cold["ms_per_step"] * 1e-3)
+        line["ms_per_step_hbm_resident"] = cold["ms_per_step"]
+        line["value_hbm_resident_is"] = ("pool-evaluations per second of the SAME step when every sweep reads its pool state from "
+                                         "HBM (steps rotate over roofline.cold.copies market copies, roofline.cold.bytes_touched bytes "
+                                         ">= 2 x the 256 MiB Infinity Cache); `value` is the cache-warm step")
+        line["config"]["hbm_resident"] = "step %.2fus kernel %.2fus frac %.3f ring %d copies %.0fMB touched" % (
+            1e3 * cold["ms_per_step"], 1e3 * cold["kernel_ms"], cold["frac"], cold["copies"], cold["bytes_touched"] / 1e6)
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check
     if route_sharded is not None:
@@ -353,6 +509,15 @@ def main():
     if sr is not None:
         sr.close()
     sb.close()
+    if (rank == 0 and world == 1 and not use_dist and args.workload == "config3" and not args.no_cpu and not args.no_configs
+            and not args.cold_only and not args.no_cold and not os.environ.get("CFMM_BENCH_CHILD")):
+        line["configs"] = other_configs(args, local_rank, args.configs_budget_s)
+        line["configs_is"] = ("the other BASELINE configurations measured in this same run (K = 20, W = 5 each): ms/step, HBM-resident "
+                              "kernel time + frac, bus_frac from the committed PMC bytes, parity at fixed v vs the CPU restatement "
+                              "and route! vs the Fortran L-BFGS-B fixture; `config.cfg_*` repeat them as one-line strings")
+        for k, rec in line["configs"].items():
+            if isinstance(rec, dict):
+                line["config"]["cfg_" + k] = summary_string(rec)
     if rank == 0:
         print(json.dumps(line))
     if use_dist:

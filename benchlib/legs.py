@@ -192,18 +192,28 @@ def roofline_record(sb, args, ms_per_step, sweep_ms, reduce_ms, elapsed2, cold, 
     the REFERENCE's per-pool bytes (SURVEY.md §8d: pool state + 32 B of Δ/Λ rows) -- an accounting unit, not bandwidth;
     `bus_frac` prices the bytes the PMC counters saw the launch move (the fraction of the bus), `layout` the bytes this
     layout has to move by construction; `step_frac` the WHOLE step (sweep + fold + boundaries) in the reference's bytes."""
+    from .shard import L3_BYTES
     from .workloads import HBM_PEAK_GBS, alg_bytes
     be, n, materialize = sb.be, sb.n, sb.materialize
     bytes_per_launch = alg_bytes(sb.batches, materialize, sb.v)
     achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     warm = {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "kernel_ms": sweep_ms}
     if args.cold_only and sb.ring is not None:
-        hbm, resid = dict(warm), "hbm-resident: the timed steps rotate over > 300 MB of market copies (--cold-only)"
+        per_copy, copies = sb.market_copies()
+        ok = copies * per_copy >= 2 * L3_BYTES and len(sb.ring) == copies
+        hbm = dict(warm)
+        resid = ("%s: the timed steps rotate over %d market copies = %.0f MB touched (--cold-only)"
+                 % ("hbm-resident" if ok else "NOT proven hbm-resident", len(sb.ring), len(sb.ring) * per_copy / 1e6))
+        cold = {"copies": len(sb.ring), "touched_per_copy": per_copy, "bytes_touched": len(sb.ring) * per_copy, "hbm_resident": bool(ok),
+                "kernel_ms": sweep_ms, "ms_per_step": ms_per_step}
         warm = None
     elif cold is not None:
         hbm = {"achieved": cold["achieved"], "frac": cold["frac"], "kernel_ms": cold["kernel_ms"]}
-        resid = ("hbm-resident: cold pass over %d market copies (%.0f MB rotated) after the timed region; the timed "
-                 "region itself sweeps one cache-resident market (see `warm`)" % (cold["copies"], cold["bytes_rotated"] / 1e6))
+        resid = ("%s: cold pass over %d market copies (%.0f MB touched per rotation = %.1f x the 256 MiB Infinity Cache; sized by the "
+                 "bytes a sweep really moves, not by the reference-layout bytes) after the timed region; the timed region "
+                 "itself sweeps one cache-resident market (see `warm`)"
+                 % ("hbm-resident" if cold.get("hbm_resident") else "NOT proven hbm-resident (ring smaller than 2 x the cache)",
+                    cold["copies"], cold["bytes_touched"] / 1e6, cold["bytes_touched"] / L3_BYTES))
     else:
         hbm, resid = dict(warm), "cache-warm only (no cold pass in this run: --no-cold)"
     compact = bool(materialize and be.ctx.get_option("compact_trades"))
@@ -227,5 +237,5 @@ def roofline_record(sb, args, ms_per_step, sweep_ms, reduce_ms, elapsed2, cold, 
             "reduce_kernel_ms": reduce_ms, "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
             "how": "kernel_ms = mean duration of the sweep launches (slowest rank), from hipEvent pairs written by the "
                    "command processor at each kernel's start and stop (hipExtLaunchKernel) on the launch stream; the rocprofv3 "
-                   "averages of the same commands are profiles/r04_*_kernel_stats.csv (warm: --no-cold runs; hbm-resident: "
+                   "averages of the same commands are profiles/r05_*_kernel_stats.csv (warm: --no-cold runs; hbm-resident: "
                    "--cold-only runs) -- DESIGN.md quotes those and gives this clock in parentheses"}

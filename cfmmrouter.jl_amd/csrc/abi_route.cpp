@@ -2,6 +2,8 @@
 // device evaluations, with the reference's objectives (src/objectives.jl:51-146), bounds (src/router.jl:67-70) and
 // v-cache rule (:74, :92).  Also the bare solver for host-side callers.
 #include "ctx.h"
+
+#include <new>
 #include "lbfgsb.h"
 
 #include <algorithm>
@@ -155,10 +157,33 @@ int cfmm_route(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec,
     return CFMM_OK;
 }
 
+static int polish_body(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec, int32_t objective_index, double* v,
+                       int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info);
+
+// EXPERIMENTAL (not one of the reference's verbs; include/cfmm_amd.h, experimental section).  Dense n x n Jacobian on the
+// host + n + 1 sweeps: bounded to LDS-path markets (n_tokens <= 8192: 512 MiB of Jacobian at most), no exception crosses
+// the C ABI.
 int cfmm_polish(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec, int32_t objective_index, double* v,
                 int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info)
 {
     if (!c) return CFMM_ERR_INVALID_ARG;
+    if (global_bins(c))
+        return fail(c, CFMM_ERR_UNSUPPORTED, "cfmm_polish builds a dense n_tokens x n_tokens Jacobian: markets with more than %d "
+                                             "tokens are not supported", kMaxLdsTokens);
+    try {
+        return polish_body(c, objective_kind, objective_vec, objective_index, v, max_iters, rel_step, psi_out, info);
+    } catch (const std::bad_alloc&) {
+        armed_cancel(c);
+        return fail(c, CFMM_ERR_HIP, "cfmm_polish: out of host memory (dense %d x %d Jacobian)", c->n, c->n);
+    } catch (...) {
+        armed_cancel(c);
+        return fail(c, CFMM_ERR_STATE, "cfmm_polish: unexpected exception");
+    }
+}
+
+static int polish_body(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec, int32_t objective_index, double* v,
+                       int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info)
+{
     const int n = c->n;
     if (!objective_vec || !v) return fail(c, CFMM_ERR_INVALID_ARG, "objective vector / v is null");
     if (objective_kind != CFMM_OBJ_LINEAR_NONNEGATIVE && objective_kind != CFMM_OBJ_BASKET_LIQUIDATION)
@@ -197,9 +222,9 @@ int cfmm_polish(cfmm_ctx* c, int32_t objective_kind, const double* objective_vec
     int rc = gradient(x, G);
     if (rc != CFMM_OK) return rc;
     // forward-difference Jacobian (column j = dG / dv_j), row-major J[i*n + j]
-    std::vector<double> J((size_t)n * n);
+    std::vector<double> J(max_iters > 0 ? (size_t)n * n : 0);   // (max_iters <= 0: the residual at v alone, no Jacobian sweeps)
     xt = x;
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < n && max_iters > 0; ++j) {
         xt[j] = x[j] * (1.0 + rel_step);
         rc = gradient(xt, Gt);
         if (rc != CFMM_OK) return rc;

@@ -344,6 +344,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         a.copies = bin_copies(c, g.block);
         a.compact = (c->opt_compact_trades != 0 && !gb) ? 1 : 0;
         a.partials = c->d_partials + (size_t)g.row_off * row_width(c);
+        a.row_pitch = row_width(c);
         a.reverse = c->opt_alternate != 0 ? (int)(c->sweep_count & 1) : 0;
         a.arm_word = arm_word;
         a.arm_seq = arm_seq;
@@ -368,6 +369,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             const Segment& s = c->segs[(size_t)g.first + k];
             fast = s.fast_ok != 0 && !(s.kind == CFMM_KIND_GEOMEAN && c->opt_geomean_exact != 0);
         }
+        // ... which the host knows for host-pointer sweeps and cfmm_route (pre-armed launches: armed_eval checks the prices before
+        // it signals and cancels a launch whose prices turn out to be outside); a device-pointer sweep (prices unknown) gets the
+        // kernel that carries both loops and decides per block from the prices it stages
+        const int arith = !fast ? 0 : (price_window == kPricesUnknown && arm_seq == 0 && c->opt_debug_dev_trust == 0) ? 2 : 1;
         const auto gbase_of = [&](const Segment& s) { return a.gtab_n ? s.gbase : -1; };   // -1: fees from the gamma array
         auto product_of = [&](const Segment& s) { return ProductPools{s.R, s.gamma, s.Ai, s.pk, gbase_of(s)}; };
         auto geomean_of = [&](const Segment& s) {
@@ -402,7 +407,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
                 default: ms.pools.u = univ3_of(s); break;
                 }
             }
-            LaunchCfg cfg{g.block, g.grid, lds, fast, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, lds, arith, ea, eb};
             e = launch_multi(ma, cfg, materialize, c->stream);
         } else {
             const Segment& s = c->segs[(size_t)g.first];
@@ -411,7 +416,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.Lambda = materialize ? c->d_lambda + s.trade_off : nullptr;
             a.Over = materialize ? c->d_over + s.trade_off : nullptr;
             a.gflow = gb ? c->d_flow + s.trade_off : nullptr;
-            LaunchCfg cfg{g.block, g.grid, lds, fast, ea, eb};
+            LaunchCfg cfg{g.block, g.grid, lds, arith, ea, eb};
             switch (s.kind) {
             case CFMM_KIND_PRODUCT: e = launch_sweep(product_of(s), a, cfg, materialize, c->stream); break;
             case CFMM_KIND_GEOMEAN: e = launch_sweep(geomean_of(s), a, cfg, materialize, c->stream); break;
@@ -443,7 +448,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         ps.timeout_ticks = c->peer_timeout_ticks;
         ps.host = ho;
         ps.arm = ArmWord{arm_word, arm_seq};
-        hipError_t e = launch_reduce_gather(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, ps,
+        hipError_t e = launch_reduce_gather(c->d_partials, (int)c->rows_total, c->n + 1, row_width(c), d_out, c->stream, ps,
                                             bracket ? nullptr : ra, bracket ? nullptr : rb);
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "fold + gather launch failed: %s", hipGetErrorString(e));
     } else if (c->rows_total > 0) {
@@ -452,7 +457,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             e = launch_gather(c->d_chunks, c->d_entries, reinterpret_cast<const double*>(c->d_flow), c->d_chunk_sums,
                               c->n_chunks, c->d_tok_chunk_off, d_out, c->n, c->d_partials, (int)c->rows_total, c->stream);
         } else {
-            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, d_out, c->stream, bracket ? nullptr : ra,
+            e = launch_reduce(c->d_partials, (int)c->rows_total, c->n + 1, row_width(c), d_out, c->stream, bracket ? nullptr : ra,
                               bracket ? nullptr : rb, ho, ArmWord{arm_word, arm_seq});
         }
         if (e != hipSuccess) return fail(c, CFMM_ERR_HIP, "reduce launch failed: %s", hipGetErrorString(e));
@@ -498,16 +503,18 @@ bool prices_in_fast_window(const double* v, int n)
 unsigned long long take_flags(cfmm_ctx* c, unsigned long long mask)
 {
     if (!c->h_stage) return 0;
-    volatile unsigned long long* w = reinterpret_cast<volatile unsigned long long*>(c->h_stage + c->flag_off);
-    const unsigned long long f = *w & mask;
-    if (f) *w = *w & ~f;
-    return f;
+    // atomic on the mapped word: launches queued behind the current one may report (system-scope fetch_or over PCIe) while the
+    // host clears -- a plain read-modify-write could lose their bit
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(c->h_stage + c->flag_off);
+    if ((__atomic_load_n(w, __ATOMIC_ACQUIRE) & mask) == 0) return 0;
+    return __atomic_fetch_and(w, ~mask, __ATOMIC_ACQ_REL) & mask;
 }
 
 // First half of a host-pointer sweep: stage v, enqueue the evaluation (asynchronous).
 int host_sweep_begin(cfmm_ctx* c, const double* v, bool materialize)
 {
     HIP_TRY(c, hipSetDevice(c->device));
+    (void)take_flags(c, kFlagWindow);     // a stale report must not label a later overflow of THIS call
     std::memcpy(c->h_stage, v, (size_t)c->n * sizeof(double));
     if (materialize) {
         c->trade_v.assign(v, v + c->n);   // the prices the device trades belong to (update_reserves!)
@@ -564,10 +571,9 @@ int take_host_out(cfmm_ctx* c)
             c->have_out = false;
             (void)hipStreamSynchronize(c->stream);
             const unsigned long long why = take_flags(c, kFlagWindow);
-            if (why & kFlagWindow) {   // (cannot happen on a host-pointer sweep: the host checked these prices)
-                c->dev_slow = true;
-                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}: a price lies outside the window of the fast arithmetic");
-            }
+            if (why & kFlagWindow)     // (a fast kernel met prices the host had vouched for: cannot happen unless v changed under the call)
+                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}: a price lies outside the window of the fast arithmetic "
+                                               "(the price vector changed while the call ran?)");
             if (!c->peers.empty())
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
                                                "publish within CFMM_AMD_PEER_TIMEOUT_S) or a shard overflowed", j);
@@ -889,16 +895,11 @@ int cfmm_sweep_dev(cfmm_ctx* c, const double* d_v, double* d_out, int materializ
     CFMM_SINGLE_ONLY(c, "cfmm_sweep_dev");
     c->have_out = false; // results live on the device; the host copy is stale
     if (materialize) c->trade_v.clear();   // the library has not seen these prices
-    // Device-pointer sweeps run the fast kernels on trust: the library cannot see these prices.  A block that stages a
-    // price outside [2^-150, 2^150] (or NaN / 0 / inf) does not compute -- it poisons {psi, acc} with NaN and reports it.
-    // The next call finds the report and fails ONCE, saying so (nothing is enqueued); from then on this context's
-    // device-pointer sweeps run the full-range kernels, which treat such prices like the reference's arithmetic does.
-    if (!c->dev_slow && (take_flags(c, kFlagWindow) & kFlagWindow)) {
-        c->dev_slow = true;
-        return fail(c, CFMM_ERR_STATE, "an earlier device-pointer sweep met a price outside [2^-150, 2^150] and delivered NaN; "
-                                       "device-pointer sweeps on this context use the full-range arithmetic from now on: repeat the call");
-    }
-    return enqueue_sweep(c, d_v, d_out, materialize != 0, false, 0, c->dev_slow ? kPricesOutside : kPricesUnknown);
+    // The library cannot see these prices: the launch carries both arithmetics and every block picks from the prices it
+    // stages (sweep_kernels.hip kArithAuto) -- prices outside [2^-150, 2^150], NaN included, take the full-range loop and
+    // propagate like the reference's arithmetic.  (Round 4 launched the fast kernels on trust and reported a refusal on a
+    // LATER call: ADVICE r4.)
+    return enqueue_sweep(c, d_v, d_out, materialize != 0, false, 0, kPricesUnknown);
 }
 
 } // extern "C"

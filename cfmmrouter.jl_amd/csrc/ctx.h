@@ -120,7 +120,7 @@ struct cfmm_ctx {
 
     double* d_v = nullptr;        // [n]
     double* d_out = nullptr;      // [n+1]
-    double* d_partials = nullptr; // [rows_cap][n+1]
+    double* d_partials = nullptr; // [rows_cap][row_width]: n+1 columns, rows padded to 128 bytes
     int64_t rows_cap = 0;
     // trade buffers [trade_cap] each.  Compact layout (option "compact_trades", default): d_delta holds ONE 16-byte
     // record per pool, d_lambda / d_over the four values of the rare pools that trade in both directions (sweep.h
@@ -155,8 +155,6 @@ struct cfmm_ctx {
     double* d_stage = nullptr;    // device address of h_stage
     size_t gran_off = 0;          // first output granule in h_stage / d_stage (doubles)
     size_t flag_off = 0;          // the sweeps' sticky report word (sweep.h kFlagWindow / kFlagGaveUp), its own 128-byte line
-    bool dev_slow = false;        // a device-pointer sweep met prices outside the window of the fast arithmetic: such sweeps
-                                  // run on the full-range kernels from then on (cfmm_sweep_dev)
     double* d_gtab = nullptr;     // [groups][kMaxFeeTable] fee tables of the launches (packed pool records)
     size_t gtab_cap = 0;
     // pre-armed evaluations of cfmm_route (sweep.h SweepArgs::arm_word): [n_pad] v, then the word, in FINE-GRAINED
@@ -194,6 +192,8 @@ struct cfmm_ctx {
     int64_t opt_stop_in_noise = 0; // cfmm_route: 1 = end the run when a line-search trial point sits on the rounding-noise floor
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
+    int64_t opt_debug_dev_trust = 0; // A/B hook: 1 = device-pointer sweeps launch the fast kernels on trust (round 4's behaviour: a price
+                                     //    outside the window poisons the output) instead of the kernels that carry both arithmetics
     int64_t opt_debug_stall_ms = 0; // test hook: the next armed evaluation is preceded by a host stall of this length (once)
     uint64_t sweep_count = 0;
 
@@ -243,7 +243,7 @@ int upload(cfmm_ctx* c, T** dst, const void* src, size_t count)
 }
 
 inline bool global_bins(const cfmm_ctx* c) { return c->n > kMaxLdsTokens; }
-inline int row_width(const cfmm_ctx* c) { return global_bins(c) ? 1 : c->n + 1; }
+inline int row_width(const cfmm_ctx* c) { return global_bins(c) ? 1 : row_pitch_of(c->n + 1); }   // doubles between partial rows
 inline bool is_parent(const cfmm_ctx* c) { return !c->shards.empty() || c->device < 0; }
 
 // abi_upload.cpp

@@ -11,7 +11,9 @@ constexpr int kMidBlock = 512;       // 8 wavefronts: small markets (one tile pe
 constexpr int kBigBlock = 1024;      // 16 wavefronts: single-family launches, few partial rows
 constexpr int kFoldBlock = 512;      // reduce_partials / reduce_gather
 constexpr int kResidentThreads = 2048 * 256; // one machine of resident threads (256 CUs x 2048)
-constexpr int kReduceCols = 8;       // tokens per fold block (one 64 B line of each partial row)
+constexpr int kReduceCols = 8;       // tokens per fold block (64 B = half a 128-byte line of each partial row; the two blocks that share
+                                     // a line run on the SAME XCD, i.e. behind the same L2: fold_colblock in sweep_kernels.hip)
+constexpr int kRowAlign = 16;        // partial rows are padded to a multiple of this many doubles (128 B)
 constexpr int kMaxLdsTokens = 8192;  // up to here the prices + one bin copy fit the 160 KiB LDS of a CU;
                                      // larger markets pull Ψ per token (sweep_body<..., GBINS=true>)
 constexpr int kGatherChunk = 512;    // incidence entries per wavefront in gather_chunks
@@ -105,7 +107,10 @@ struct SweepArgs {
     double2* Lambda;
     double2* Over;
     int compact;
-    double* partials;            // [grid][n+1] rows of this launch ([grid][1] with global bins)
+    double* partials;            // [grid][row_pitch] rows of this launch ([grid][1] with global bins)
+    int row_pitch;               // doubles between two partial rows: n+1 rounded up to a multiple of 16 (128-byte rows: a fold block's
+                                 //    64-byte column group never straddles a line; round 4's pitch of n+1 doubles shifted every row by
+                                 //    8 bytes: 1491 KiB fetched for 526 KB of rows), 1 with global bins
     double2* gflow;              // null: LDS bins; else [m] {Λ₁−Δ₁, Λ₂−Δ₂} of this segment (large markets)
     int reverse;                 // 1: every lane walks its tiles last-to-first (alternates between consecutive sweeps, so a
                                  //    sweep starts on the pool data the previous one left in the XCD's L2)
@@ -156,8 +161,10 @@ struct LaunchCfg {
     int block;                   // kMidBlock or kBigBlock
     int grid;
     size_t lds_bytes;
-    bool fast = false;           // the kernel on the fast arithmetic (sweep_kernels.hip, FASTK): every pool constant of the launch
-                                 // and -- as far as the host knows -- every price inside the kFastExp window
+    int arith = 0;               // the kernel's arithmetic (sweep_kernels.hip, FASTK): 0 = the compiler's full-range sequences,
+                                 // 1 = fast (every pool constant of the launch and -- the host KNOWS -- every price inside the
+                                 // kFastExp window), 2 = auto (pool constants inside the window, prices unknown to the host:
+                                 // device-pointer sweeps; every block picks the loop from the prices it stages)
     hipEvent_t ev_start = nullptr; // both set: the launch is timed by the command processor
     hipEvent_t ev_stop = nullptr;  // (hipExtLaunchKernel), i.e. the kernel's own execution span
 };
@@ -191,8 +198,10 @@ struct ArmWord {                 // see SweepArgs::arm_word; {nullptr, 0} = not 
     const unsigned long long* word;
     unsigned long long seq;
 };
+// rows of n1 doubles, `pitch` doubles apart (SweepArgs::row_pitch)
+inline int row_pitch_of(int n1) { return (n1 + kRowAlign - 1) / kRowAlign * kRowAlign; }
 // out[j] = sum over rows of partials[row][j], j in [0, n1); fixed summation order.
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s,
+hipError_t launch_reduce(const double* partials, int rows, int n1, int pitch, double* out, hipStream_t s,
                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, HostOut host = HostOut{nullptr, 0},
                          ArmWord arm = ArmWord{nullptr, 0});
 
@@ -210,7 +219,7 @@ struct PeerSet {
     HostOut host;                           // optional: the global {Ψ, acc} also travel to the host as granules
     ArmWord arm;                            // pre-armed evaluation: a cancelled launch publishes nothing
 };
-hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s,
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, int pitch, double* out, hipStream_t s,
                                 const PeerSet& ps, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // R <- (R + gamma*Delta) - Lambda in place; GeometricMean (Q, eta non-null): Q <- the exponents' constants for the new R;

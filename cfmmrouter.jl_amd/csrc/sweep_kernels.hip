@@ -958,17 +958,25 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
 // FASTK selects the arithmetic of the WHOLE kernel (round 4).  Rounds 1-3 compiled both tile loops into every kernel and
 // chose per block; the two copies cost 12-36 VGPRs over the larger of the two alone (ProductTwoCoin 70 vs 56 / 58,
 // UniV3 84 vs 63 / 63, the fused materialising launch 116 vs 80 / 97: profiles/r04_kernel_resources.txt), i.e. one to
-// three wavefronts per SIMD.  Now the HOST picks the kernel: the fast one when every pool constant of the launch is
-// inside the window (Segment::fast_ok, checked at upload) and the prices are too -- which it knows for host-pointer
-// sweeps and for cfmm_route, and assumes for device-pointer sweeps.  Every block of a fast kernel still checks the
-// prices it stages; outside the window it does NOT compute: it poisons its row (NaN in every column -- an error, never
-// a wrong number) and reports kFlagWindow, upon which the library switches the context's device-pointer sweeps to the
-// full-range kernels (abi_sweep.cpp).
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK, bool MULTI>
+// three wavefronts per SIMD.  Now the HOST picks the kernel wherever it can:
+//   kArithFull  the compiler's full-range sequences (fast_math = 0, pool constants or prices outside the window);
+//   kArithFast  the fast arithmetic: every pool constant of the launch is inside the window (Segment::fast_ok, checked at
+//               upload) and so are the prices -- which the host KNOWS (host-pointer sweeps, cfmm_route).  Every block still
+//               checks the prices it stages; outside the window it does NOT compute: it poisons its row (NaN in every column
+//               -- an error, never a wrong number) and reports kFlagWindow (reachable only through a pre-armed launch whose
+//               host-side check raced; abi_sweep.cpp cancels such launches before they run);
+//   kArithAuto  round 5, device-pointer sweeps (cfmm_sweep_dev): the library cannot see these prices, so the kernel carries
+//               BOTH tile loops and every block chooses from the prices it staged (block-uniform, and the same choice in every
+//               block: all stage the same vector) -- prices outside the window, NaN included, take the full-range loop and
+//               behave like the reference's arithmetic, instead of round 4's "refuse, report on a later call" protocol
+//               (ADVICE r4, medium).  Costs the registers of rounds 1-3 again, which the default geometry (4 wavefronts per
+//               SIMD) never needed.
+constexpr int kArithFull = 0, kArithFast = 1, kArithAuto = 2;
+template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK, bool MULTI>
 __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
                                               bool& poison)
 {
-    static_assert(!(GBINS && FASTK), "large-market mode runs on the compiler's sequences");
+    static_assert(!(GBINS && FASTK != kArithFull), "large-market mode runs on the compiler's sequences");
     double acc = 0.0;
     const int64_t stride = (int64_t)nblocks * BLOCK;
     const int64_t i0 = (int64_t)bid * BLOCK + threadIdx.x;
@@ -980,14 +988,20 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     const int staged = stage_prices<BLOCK, GBINS>(a, L);
     poison = (staged & kStageLive) == 0;              // a pre-armed launch that is not needed (or gave up)
     if (staged & kStageGaveUp) report(a, kFlagGaveUp);
-    if (FASTK && !poison && (staged & kStageFast) == 0) {
+    if (FASTK == kArithFast && !poison && (staged & kStageFast) == 0) {
         poison = true;                                // prices outside the window of this kernel's arithmetic
         report(a, kFlagWindow);
     }
     if (poison) left = 0;
     // next-tile prefetch: single-family launches of the two-coin families (HBM-resident -4..-6 %, cache-warm +-0.1 us); the
     // fused multi-family launch keeps the plain loop (same-box A/B on config3: -2 % HBM-resident but +1.5 % on the warm step)
-    tile_loop<Ops, MAT, BLOCK, GBINS, FASTK, Ops::kPrefetch && !MULTI>(ops, a, L, cur, i, step, left, acc);
+    constexpr bool kPre = Ops::kPrefetch && !MULTI;
+    if constexpr (FASTK == kArithAuto) {
+        if (staged & kStageFast) tile_loop<Ops, MAT, BLOCK, GBINS, true, kPre>(ops, a, L, cur, i, step, left, acc);
+        else tile_loop<Ops, MAT, BLOCK, GBINS, false, kPre>(ops, a, L, cur, i, step, left, acc);
+    } else {
+        tile_loop<Ops, MAT, BLOCK, GBINS, FASTK == kArithFast, kPre>(ops, a, L, cur, i, step, left, acc);
+    }
     return acc;
 }
 
@@ -1007,7 +1021,7 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     __syncthreads();
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
-    double* row = a.partials + (size_t)row_id * (n_cols + 1);
+    double* row = a.partials + (size_t)row_id * a.row_pitch;   // 128-byte aligned rows (SweepArgs::row_pitch)
     for (int j = tid; j < n_cols; j += BLOCK) {
         double s = L.bins[j];
         for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
@@ -1022,7 +1036,7 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
 
 // One block's share of ONE segment: tiles bid, bid+nblocks, ... of the segment's pools; its partial
 // row goes to partials[row_id].
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK, bool MULTI>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK, bool MULTI>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
@@ -1031,7 +1045,7 @@ __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, i
     finish_row<BLOCK, GBINS>(a, L, acc, row_id, poison);
 }
 
-template <class Ops, bool MAT, int BLOCK, bool GBINS, bool FASTK>
+template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 {
     sweep_body<Ops, MAT, BLOCK, GBINS, FASTK, false>(ops, a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
@@ -1039,7 +1053,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(Ops ops, SweepArgs a)
 
 // Several segments (pool families) in ONE launch, so HBM-bound ProductTwoCoin blocks and ALU-bound GeometricMean /
 // UniV3 blocks are co-resident on every CU and overlap, and the sweep pays one launch + one kernel boundary instead of nseg.
-template <bool MAT, int BLOCK, bool GBINS, bool FASTK>
+template <bool MAT, int BLOCK, bool GBINS, int FASTK>
 __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 {
     const int bidx = (int)blockIdx.x;
@@ -1087,11 +1101,31 @@ __global__ __launch_bounds__(BLOCK) void sweep_multi(MultiArgs ma)
 // ---------------------------------------------------------------------------------------------
 // Row fold: out[j] = sum over rows of partials[row][j]  (src/router.jl:81-83, :98-100 summed over blocks)
 // ---------------------------------------------------------------------------------------------
-// One block owns kReduceCols adjacent columns (one 64 B line of every row).  lane = (row-lane r,
+// One block owns kReduceCols adjacent columns (64 B = half a 128-byte line of every row; rows are 128-byte aligned,
+// SweepArgs::row_pitch).  lane = (row-lane r,
 // column c): a wavefront holds 8 row-lanes x 8 columns.  Each lane sums its rows in increasing
 // order (kBatch independent loads in flight), the row-lanes of a wavefront are folded by a fixed
 // shuffle tree, the wavefronts by a fixed-order LDS pass: bit-reproducible for a fixed geometry.
-__device__ __forceinline__ double fold_columns(const double* __restrict__ partials, int rows, int n1, int colblock, double* red)
+//
+// Block -> column group.  The two column groups of one 128-byte line are folded by two blocks; blocks are dealt round-robin
+// to the 8 XCDs (block b runs on XCD b % 8, each with its own L2), so with "column group = block index" every line of the
+// partial rows was fetched from the fabric TWICE, by two different L2s (round 4: 1491 KiB per fold for 526 KB of rows,
+// together with rows that were not line-aligned).  Here the pair of groups {2p, 2p+1} belongs to blocks b = x + 8·(2j) and
+// x + 8·(2j+1) with p = x + 8j: same XCD, consecutive deals -- the second request of a line is served by that XCD's L2
+// (or merged with the first in flight).  Grid = 16·ceil(pairs / 8) blocks; a block beyond the last group returns.
+// Placement is only a performance assumption: any placement computes the same result.
+__device__ __forceinline__ int fold_colblock(int b)
+{
+    const int x = b & 7, q = b >> 3;
+    return 2 * (x + 8 * (q >> 1)) + (q & 1);
+}
+static int fold_grid(int n1)
+{
+    const int groups = (n1 + kReduceCols - 1) / kReduceCols, pairs = (groups + 1) / 2;
+    return 16 * ((pairs + 7) / 8);
+}
+
+__device__ __forceinline__ double fold_columns(const double* __restrict__ partials, int rows, int n1, int pitch, int colblock, double* red)
 {
     constexpr int kRowLanes = kFoldBlock / kReduceCols;
     constexpr int kWaves = kFoldBlock / 64;
@@ -1106,11 +1140,11 @@ __device__ __forceinline__ double fold_columns(const double* __restrict__ partia
         for (; row + (kBatch - 1) * kRowLanes < rows; row += kBatch * kRowLanes) {
             double x[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * n1];
+            for (int b = 0; b < kBatch; ++b) x[b] = p[(size_t)(row + b * kRowLanes) * pitch];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) s += x[b];
         }
-        for (; row < rows; row += kRowLanes) s += p[(size_t)row * n1];
+        for (; row < rows; row += kRowLanes) s += p[(size_t)row * pitch];
     }
 #pragma unroll
     for (int off = 32; off >= kReduceCols; off >>= 1) s += __shfl_down(s, off, 64);
@@ -1132,17 +1166,17 @@ __device__ __forceinline__ double fold_columns(const double* __restrict__ partia
 // read-modify-write per piece at the host's memory controller (measured: 2x slower evaluations).  Columns past n1
 // travel as zeros so that the last block writes full lines too.  The host re-reads the granules until all carry the
 // tag: no drain of the output stores, no ticket, no flag word.  Wavefront 0 only; tsum valid in lanes [0, kReduceCols).
-__device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double* out, HostOut host)
+__device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, int colblock, double* out, HostOut host)
 {
     const int tid = threadIdx.x;
     if (tid >= 64) return;
-    const int col = blockIdx.x * kReduceCols + tid;
+    const int col = colblock * kReduceCols + tid;
     if (host.gran) {
         const double val = (tid < kReduceCols && col < n1) ? (ok ? tsum : __builtin_nan("")) : 0.0;
         const long long bits = __shfl(__double_as_longlong(val), (tid >> 1) & (kReduceCols - 1), 64);
         if (tid < 2 * kReduceCols) {
             const unsigned long long tag = (host.tag & 0xffffffffull) << 32, u = (unsigned long long)bits;
-            __hip_atomic_store(host.gran + 2 * (size_t)blockIdx.x * kReduceCols + tid,
+            __hip_atomic_store(host.gran + 2 * (size_t)colblock * kReduceCols + tid,
                                tag | ((tid & 1) ? (u >> 32) : (u & 0xffffffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     } else if (tid < kReduceCols && col < n1) {
@@ -1151,15 +1185,17 @@ __device__ __forceinline__ void fold_finish(double tsum, bool ok, int n1, double
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int rows, int n1,
+__global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restrict__ partials, int rows, int n1, int pitch,
                                                          double* __restrict__ out, HostOut host, ArmWord arm)
 {
     __shared__ double red[(BLOCK / 64) * kReduceCols];
+    const int colblock = fold_colblock((int)blockIdx.x);
+    if (colblock * kReduceCols >= n1) return;             // (block-uniform) padding of the grid to whole XCD deals
     // the fold of a pre-armed evaluation that was cancelled (or never got its prices) has nothing to publish; the
     // word cannot change between the threads' loads: the host moves on only after this launch's outputs
     if (arm.word && __hip_atomic_load(arm.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != arm.seq) return;
-    const double tsum = fold_columns(partials, rows, n1, blockIdx.x, red);
-    fold_finish(tsum, true, n1, out, host);
+    const double tsum = fold_columns(partials, rows, n1, pitch, colblock, red);
+    fold_finish(tsum, true, n1, colblock, out, host);
 }
 
 // Fold + all-reduce in one launch (sharded runs, see sweep.h).  The exchange uses self-validating
@@ -1172,19 +1208,21 @@ __global__ __launch_bounds__(BLOCK) void reduce_partials(const double* __restric
 // launch, which waited for every peer's seq+1 granules, i.e. for every peer's seq launch -- the one
 // that read gran[parity] -- to have completed.  Waits are bounded by wall-clock time (NaN output).
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict__ partials, int rows, int n1,
+__global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict__ partials, int rows, int n1, int pitch,
                                                        double* __restrict__ out, PeerSet ps)
 {
     __shared__ double red[(BLOCK / 64) * kReduceCols];
+    const int colblock = fold_colblock((int)blockIdx.x);
+    if (colblock * kReduceCols >= n1) return;             // (block-uniform) padding of the grid to whole XCD deals
     // a cancelled pre-armed evaluation is cancelled on EVERY rank (the ranks run the same solver in lockstep):
     // nobody publishes, nobody waits, and the sequence number is reused by the next launch
     if (ps.arm.word && __hip_atomic_load(ps.arm.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ps.arm.seq) return;
-    const double tsum = fold_columns(partials, rows, n1, blockIdx.x, red);
+    const double tsum = fold_columns(partials, rows, n1, pitch, colblock, red);
     const int tid = threadIdx.x;
     if (tid >= 64) return;                                // the exchange is wavefront 0's business
     const int parity = (int)(ps.seq & 1ull);
     const unsigned long long tag = (ps.seq % 0xffffffffull + 1ull) << 32;   // never 0 (= an empty buffer)
-    const int col = blockIdx.x * kReduceCols + tid;
+    const int col = colblock * kReduceCols + tid;
     if (tid < kReduceCols && col < n1 && ps.world > 1) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(tsum);
         unsigned long long* g = ps.gran[ps.rank] + 2 * ((long long)parity * ps.count + col);
@@ -1193,7 +1231,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict_
     }
     // lane = (peer slot q, column c): 8 peers x 8 columns per pass, two passes cover kMaxPeers = 16
     const int q = tid / kReduceCols, c = tid % kReduceCols;
-    const int colc = blockIdx.x * kReduceCols + c;
+    const int colc = colblock * kReduceCols + c;
     const double own = __shfl(tsum, c, 64);
     double x[2] = {0.0, 0.0};
     bool ok = true;
@@ -1218,7 +1256,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_gather(const double* __restrict_
     ok = __all(ok);
     double s = 0.0;                                       // rank order on every rank: bit-identical results
     for (int p = 0; p < ps.world; ++p) s += __shfl(p < 8 ? x[0] : x[1], (p & 7) * kReduceCols + c, 64);
-    fold_finish(s, ok, n1, out, ps.host);
+    fold_finish(s, ok, n1, colblock, out, ps.host);
 }
 
 // Large-market Ψ (see sweep_body<..., GBINS = true>).  entries[] lists, token by token, the flat
@@ -1299,9 +1337,9 @@ size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab
     return words * sizeof(double);
 }
 
-// Kernel instantiations (round 4: 52).  Per family {fast, full-range} x {materialising, fused} x {512, 1024 threads};
+// Kernel instantiations (round 5: 68).  Per family {full-range, fast, auto} x {materialising, fused} x {512, 1024 threads};
 // the reference-order GeometricMean forms and the large-market mode (GBINS, 512 threads) run full-range only.
-template <class Ops, bool FASTK>
+template <class Ops, int FASTK>
 static hipError_t set_lds_attr(size_t bytes)
 {
     hipError_t e;
@@ -1314,7 +1352,7 @@ static hipError_t set_lds_attr(size_t bytes)
     return hipSuccess;
 }
 
-template <int B, bool FASTK>
+template <int B, int FASTK>
 static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid), b(B);
@@ -1322,18 +1360,24 @@ static void launch_multi_b(const MultiArgs& ma, const LaunchCfg& c, bool mat, hi
     else launch_k(&sweep_multi<false, B, false, FASTK>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
 }
 
+template <int B>
+static void launch_multi_a(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
+{
+    if (c.arith == kArithFast) launch_multi_b<B, kArithFast>(ma, c, mat, s);
+    else if (c.arith == kArithAuto) launch_multi_b<B, kArithAuto>(ma, c, mat, s);
+    else launch_multi_b<B, kArithFull>(ma, c, mat, s);
+}
+
 hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     if (ma.common.gflow) {   // large-market mode: kMidBlock, full-range arithmetic
         dim3 g(c.grid), b(kMidBlock);
-        if (mat) launch_k(&sweep_multi<true, kMidBlock, true, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
-        else launch_k(&sweep_multi<false, kMidBlock, true, false>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        if (mat) launch_k(&sweep_multi<true, kMidBlock, true, kArithFull>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
+        else launch_k(&sweep_multi<false, kMidBlock, true, kArithFull>, g, b, c.lds_bytes, s, c.ev_start, c.ev_stop, ma);
     } else if (c.block == kBigBlock) {
-        if (c.fast) launch_multi_b<kBigBlock, true>(ma, c, mat, s);
-        else launch_multi_b<kBigBlock, false>(ma, c, mat, s);
+        launch_multi_a<kBigBlock>(ma, c, mat, s);
     } else {
-        if (c.fast) launch_multi_b<kMidBlock, true>(ma, c, mat, s);
-        else launch_multi_b<kMidBlock, false>(ma, c, mat, s);
+        launch_multi_a<kMidBlock>(ma, c, mat, s);
     }
     return hipGetLastError();
 }
@@ -1345,20 +1389,24 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     em = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_multi<MAT, B, false, F>),           \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);         \
     if (em != hipSuccess) return em;
-    CFMM_SETM(true, kBigBlock, true) CFMM_SETM(false, kBigBlock, true) CFMM_SETM(true, kMidBlock, true) CFMM_SETM(false, kMidBlock, true)
-    CFMM_SETM(true, kBigBlock, false) CFMM_SETM(false, kBigBlock, false) CFMM_SETM(true, kMidBlock, false) CFMM_SETM(false, kMidBlock, false)
+#define CFMM_SETM4(F) CFMM_SETM(true, kBigBlock, F) CFMM_SETM(false, kBigBlock, F) CFMM_SETM(true, kMidBlock, F) CFMM_SETM(false, kMidBlock, F)
+    CFMM_SETM4(kArithFull) CFMM_SETM4(kArithFast) CFMM_SETM4(kArithAuto)
+#undef CFMM_SETM4
 #undef CFMM_SETM
     hipError_t e;
-    if ((e = set_lds_attr<ProductOps, true>(max_lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds_attr<ProductOps, false>(max_lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds_attr<GeoMeanOps, false>(max_lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds_attr<GeoMeanLogOps, true>(max_lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds_attr<GeoMeanLogOps, false>(max_lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds_attr<UniV3Ops, true>(max_lds_bytes)) != hipSuccess) return e;
-    return set_lds_attr<UniV3Ops, false>(max_lds_bytes);
+    if ((e = set_lds_attr<ProductOps, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<ProductOps, kArithFast>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<ProductOps, kArithAuto>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanOps, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanLogOps, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanLogOps, kArithFast>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<GeoMeanLogOps, kArithAuto>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<UniV3Ops, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<UniV3Ops, kArithFast>(max_lds_bytes)) != hipSuccess) return e;
+    return set_lds_attr<UniV3Ops, kArithAuto>(max_lds_bytes);
 }
 
-template <class Ops, bool FASTK>
+template <class Ops, int FASTK>
 static void launch_any_f(const Ops& ops, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
     dim3 g(c.grid);
@@ -1379,13 +1427,14 @@ static hipError_t launch_any(const Ops& ops, const SweepArgs& a, const LaunchCfg
     if (a.gflow) { // large-market mode: kMidBlock, full-range arithmetic
         dim3 g(c.grid);
         hipEvent_t e0 = c.ev_start, e1 = c.ev_stop;
-        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, true, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
-        else launch_k(&sweep_kernel<Ops, false, kMidBlock, true, false>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        if (mat) launch_k(&sweep_kernel<Ops, true, kMidBlock, true, kArithFull>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
+        else launch_k(&sweep_kernel<Ops, false, kMidBlock, true, kArithFull>, g, dim3(kMidBlock), c.lds_bytes, s, e0, e1, ops, a);
     } else if constexpr (HAS_FAST) {
-        if (c.fast) launch_any_f<Ops, true>(ops, a, c, mat, s);
-        else launch_any_f<Ops, false>(ops, a, c, mat, s);
+        if (c.arith == kArithFast) launch_any_f<Ops, kArithFast>(ops, a, c, mat, s);
+        else if (c.arith == kArithAuto) launch_any_f<Ops, kArithAuto>(ops, a, c, mat, s);
+        else launch_any_f<Ops, kArithFull>(ops, a, c, mat, s);
     } else {
-        launch_any_f<Ops, false>(ops, a, c, mat, s);
+        launch_any_f<Ops, kArithFull>(ops, a, c, mat, s);
     }
     return hipGetLastError();
 }
@@ -1404,11 +1453,11 @@ hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg
     return launch_any(UniV3Ops{p}, a, c, mat, s);
 }
 
-hipError_t launch_reduce(const double* partials, int rows, int n1, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+hipError_t launch_reduce(const double* partials, int rows, int n1, int pitch, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
                          HostOut host, ArmWord arm)
 {
-    dim3 g((n1 + kReduceCols - 1) / kReduceCols);
-    launch_k(&reduce_partials<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, out, host, arm);
+    dim3 g(fold_grid(n1));
+    launch_k(&reduce_partials<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, pitch, out, host, arm);
     return hipGetLastError();
 }
 
@@ -1493,11 +1542,11 @@ hipError_t launch_expand_trades(const double2* rec, const double2* ovA, const do
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_gather(const double* partials, int rows, int n1, double* out, hipStream_t s, const PeerSet& ps,
+hipError_t launch_reduce_gather(const double* partials, int rows, int n1, int pitch, double* out, hipStream_t s, const PeerSet& ps,
                                 hipEvent_t e0, hipEvent_t e1)
 {
-    dim3 g((n1 + kReduceCols - 1) / kReduceCols);
-    launch_k(&reduce_gather<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, out, ps);
+    dim3 g(fold_grid(n1));
+    launch_k(&reduce_gather<kFoldBlock>, g, dim3(kFoldBlock), 0, s, e0, e1, partials, rows, n1, pitch, out, ps);
     return hipGetLastError();
 }
 

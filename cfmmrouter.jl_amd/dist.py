@@ -131,7 +131,11 @@ class PeerGuard:
     def self_check(self, n_tokens, sweeps=3, rtol=1e-12):
         import os
         torch, dist = self._torch, self._dist
+        # Every rank runs the SAME sequence of collectives whatever happens locally: an iteration that raises
+        # still takes part in that iteration's all-reduce (on a NaN-filled tensor), so no rank ever sits in the SUM
+        # all-reduce of n_tokens + 1 doubles while another one is already in the vote's MIN all-reduce of one.
         ok = True
+        out = ref = stream = None
         try:
             with torch.cuda.device(self.cuda):
                 j = torch.arange(n_tokens, dtype=torch.float64, device=self.cuda)
@@ -139,7 +143,14 @@ class PeerGuard:
                 ref = torch.zeros(n_tokens + 1, dtype=torch.float64, device=self.cuda)
                 stream = torch.cuda.current_stream(self.cuda)
                 self.ctx.set_stream(stream.cuda_stream)
-                for k in range(sweeps):
+        except Exception:
+            ok = False
+        for k in range(sweeps):
+            r = None
+            try:
+                if not ok:
+                    raise RuntimeError("set-up failed")
+                with torch.cuda.device(self.cuda):
                     v = torch.exp(0.2 * torch.sin(j * (0.7 + k)))            # positive, off the no-arbitrage manifold
                     self.ctx.set_peers(self.peers.ptrs, self.world, self.rank, k)
                     self.ctx.sweep_dev(v.data_ptr(), out.data_ptr(), False)
@@ -147,18 +158,21 @@ class PeerGuard:
                     self.ctx.sweep_dev(v.data_ptr(), ref.data_ptr(), False)
                     stream.synchronize()
                     r = ref.cpu() if self.device.type == "cpu" else ref
-                    dist.all_reduce(r, group=self.group)
-                    r = r.to(self.cuda)
-                    got_ok = bool(torch.isfinite(out).all()) and \
-                        float((out - r).abs().max()) <= rtol * max(float(r.abs().max()), 1e-300)
-                    ok = ok and got_ok
-                self.ctx.reset_stream()
-        except Exception:
-            ok = False
-            try:
-                self.ctx.reset_stream()
             except Exception:
-                pass
+                ok = False
+                r = torch.full((n_tokens + 1,), float("nan"), dtype=torch.float64, device=self.device)
+            try:
+                dist.all_reduce(r, group=self.group)        # the iteration's collective: always, on every rank
+                if ok:
+                    r = r.to(self.cuda)
+                    ok = bool(torch.isfinite(out).all()) and bool(torch.isfinite(r).all()) and \
+                        float((out - r).abs().max()) <= rtol * max(float(r.abs().max()), 1e-300)
+            except Exception:
+                ok = False
+        try:
+            self.ctx.reset_stream()
+        except Exception:
+            pass
         if os.environ.get("CFMM_AMD_PEER_SELFTEST_FAIL") == str(self.rank):   # test hook: this rank reports a disagreement
             ok = False
         return self.vote(ok), sweeps

@@ -98,8 +98,8 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     price or a fee reuse a reciprocal refined once per token / fee tier: same bits, ~half the
  *                     instructions; the log-space GeometricMean form -- within 1e-12 of the reference either way --
  *                     also evaluates its exponential with an own < 1 ulp polynomial instead of the device library's;
- *                     anything outside the window runs the full-range kernels -- see cfmm_sweep_dev for the one case
- *                     the library cannot decide beforehand;
+ *                     anything outside the window runs the full-range arithmetic -- device-pointer sweeps, whose prices
+ *                     the library cannot see, decide per block inside the launch (cfmm_sweep_dev);
  *                     0: the compiler's sequences and the library's exp everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
  *                     with pow in the reference's operation order instead of the default log-space form; both are within
  *                     1e-12 of the reference), "alternate" (default 1: consecutive evaluations walk every lane's tiles in
@@ -198,12 +198,11 @@ int cfmm_dual_value(cfmm_ctx* ctx, double* acc);
 
 /* d_v: n_tokens device doubles (must be finite and > 0, src/cfmms.jl:129: the library cannot validate device
  * memory; non-positive prices give undefined trades).  The library cannot see these prices, so with "fast_math" (default)
- * the sweep runs the fast-arithmetic kernels on trust, and their blocks verify: if any price lies outside
- * [2^-150, 2^150] (NaN, 0 and infinities included) NOTHING is computed -- d_out is all NaN, an error, never a wrong
- * number -- and the NEXT cfmm_sweep_dev on the context fails once with CFMM_ERR_STATE saying so; from then on the
- * context's device-pointer sweeps run the full-range kernels, under which a NaN price propagates into the trades and
- * psi of every pool that touches the token exactly as the reference's arithmetic does.  ("fast_math" = 0 selects those
- * kernels from the start; host-pointer calls and cfmm_route choose per call, from the prices they are given.)
+ * the launch carries BOTH arithmetics and every block picks from the prices it stages: inside [2^-150, 2^150] the fast
+ * one, anything else -- NaN included -- the compiler's full-range sequences, under which a NaN price propagates into the
+ * trades and psi of every pool that touches the token exactly as the reference's arithmetic does.  The call never refuses
+ * and never changes the context's state.  (Round 4 launched the fast kernels on trust and reported a refusal on a LATER
+ * call; host-pointer calls and cfmm_route choose the kernel per call, from the prices they are given.)
  * d_out: n_tokens+1 device doubles = {psi..., acc}: the
  * buffer a sharded run all-reduces (one collective per evaluation).  Asynchronous on the
  * context's stream.  materialize != 0: also write Delta/Lambda (find_arb! semantics). */

@@ -6,9 +6,10 @@ cpu_baseline leg may import this module.  The shipped package (cfmmrouter.jl_amd
 All index arguments of this wrapper are 0-based (the harness converts the reference's 1-based
 `Ai`).  Pair arrays are float64 / int32 of shape [m, 2], C-contiguous.
 
-`route_oracle` restates route! (src/router.jl:58-108) on top of SciPy's L-BFGS-B, which is a C
-translation of the same Fortran L-BFGS-B 3.0 that LBFGSB.jl wraps.  No reference test pins the
-outer loop numerically, so route!-level results from this function are "parity unpinned".
+`route_oracle` restates route! (src/router.jl:58-108) on top of the running interpreter's SciPy
+L-BFGS-B (1.15 here: a C translation of the Fortran L-BFGS-B 3.0 that LBFGSB.jl wraps).  The
+outer loop's PIN is elsewhere: tests/golden/route_fortran.npz, runs of the Fortran code itself
+(tests/golden/make_route_golden.py, tests/test_route_fortran_pin.py).
 """
 from __future__ import annotations
 
@@ -331,6 +332,31 @@ class PoolSet:
             if kind == "univ3" and "current_tick" not in s:
                 s["current_tick"] = univ3_current_ticks(s["current_price"], s["tick_off"], s["lower_ticks"])
         self.m = self.Ai.shape[0]
+
+    def sweep_into(self, v, D, Lm, nthreads=1):
+        """find_arb!(r, v) into the caller's [m, 2] arrays (the reference overwrites r.Δs / r.Λs in place,
+        src/router.jl:40): no allocation, no concatenation -- bench.py's cpu_baseline times this."""
+        v = _f64(v)
+        L, lo = lib(), 0
+        for kind, s in self.segments:
+            m = np.asarray(s["gamma"]).size
+            d, l = D[lo:lo + m], Lm[lo:lo + m]
+            c = s.setdefault("_c", {})     # contiguous typed views of the inputs, converted once
+            def arr(name, dt=np.float64):
+                if name not in c:
+                    c[name] = np.ascontiguousarray(s[name], dtype=dt)
+                return c[name]
+            if kind == "product":
+                L.oracle_sweep_product(m, _p(arr("R")), _p(arr("gamma")), _p(arr("Ai", np.int32)), _p(v), _p(d), _p(l), int(nthreads))
+            elif kind == "geomean":
+                L.oracle_sweep_geomean(m, _p(arr("R")), _p(arr("w")), _p(arr("gamma")), _p(arr("Ai", np.int32)), _p(v), _p(d), _p(l),
+                                       int(nthreads))
+            else:
+                L.oracle_sweep_univ3(m, _p(arr("current_price")), _p(arr("current_tick", np.int64)), _p(arr("gamma")),
+                                     _p(arr("Ai", np.int32)), _p(arr("tick_off", np.int64)), _p(arr("lower_ticks")),
+                                     _p(arr("liquidity")), _p(v), _p(d), _p(l), int(nthreads))
+            lo += m
+        return D, Lm
 
     def sweep(self, v, nthreads=1):
         Ds, Ls = [], []
