@@ -29,6 +29,30 @@ def alg_bytes(batches, materialize=True, v=None):
     return tot
 
 
+L3_BYTES = 256 * 2 ** 20      # Infinity Cache (MI355X_MICROARCH.md, memory hierarchy)
+
+
+def touched_bytes(batches, materialize=True):
+    """Bytes ONE sweep moves over the L2 <-> fabric boundary in THIS library's packed layout, by construction: ProductTwoCoin
+    24 B read + 16 B trade record, GeometricMean 48 + 16, UniV3 56 (+ 16 B walk spans on multi-tick segments) + 16 -- a LOWER
+    bound (the scattered walk records of multi-tick ladders are not counted).  Sizes the HBM-resident ring."""
+    mat = 16 if materialize else 0
+    tot = 0
+    for b in batches:
+        if b.kind == KIND_PRODUCT:
+            tot += len(b) * (24 + mat)
+        elif b.kind == KIND_GEOMEAN:
+            tot += len(b) * (48 + mat)
+        else:
+            tot += len(b) * (56 + (16 if b.lower_ticks.size > 2 * len(b) else 0) + mat)
+    return int(tot)
+
+
+def ring_copies(per_copy):
+    """copies of a market such that the ring's touched bytes are >= 2 x the Infinity Cache"""
+    return int(np.ceil(2 * L3_BYTES / per_copy)) + 1
+
+
 # name: (description, n_tokens, [(generator, pools per GPU (weak) = pools in total (strong), kwargs)])
 WORKLOADS = {
     "config2": ("100k ProductTwoCoin pools, 64 tokens, LinearNonnegative arbitrage", 64,

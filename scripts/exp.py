@@ -1,7 +1,7 @@
 """Option A/B runs on the GPU box: python scripts/exp.py WORKLOAD "k=v,k=v" "k=v" ...
 Prints, per option set: wall µs per step (K back-to-back device-resident sweeps, stream-synced),
 sweep-kernel and fold-kernel µs (hipExtLaunchKernel events), materialising and fused.
-COLD=1: the sweeps rotate over > 320 MB of market copies (pool state from HBM instead of the Infinity Cache)."""
+COLD=1: the sweeps rotate over market copies whose TOUCHED bytes are >= 2 x the 256 MiB Infinity Cache (pool state from HBM)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
@@ -19,8 +19,8 @@ v_t = torch.from_numpy(v).to("cuda"); out_t = torch.zeros(n + 1, dtype=torch.flo
 K = int(os.environ.get("K", "200"))
 print(f"# {name}: {desc}")
 COLD = os.environ.get("COLD", "0") == "1"
-per_copy = bench.alg_bytes(batches, True)
-copies = int(np.ceil(320e6 / per_copy)) + 1 if COLD else 1
+per_copy = bench.touched_bytes(batches, True)     # the packed layout's own bytes (a lower bound): ring >= 2 x the Infinity Cache
+copies = bench.ring_copies(per_copy) if COLD else 1
 for spec in sys.argv[2:] or [""]:
     ring = [cr.DeviceBackend(n, batches) for _ in range(copies)]
     for b_ in ring:
