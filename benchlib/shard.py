@@ -35,8 +35,14 @@ class ShardBench:
         self.peer, self.fused_peer, self.peer_ptrs, self.n_fused = None, False, None, 0
         self.steps_run = 0
         self.ring, self.ring_pos = None, 0
+        self.lib_rccl = False
         if use_dist and not args.rccl and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
             self.setup_peers()
+        if use_dist and args.rccl and dist.get_backend() == "nccl":
+            # --rccl: the collective through the library's own RCCL entry points (cfmm_rccl_init_rank: ncclAllReduce behind
+            # every fold, on the sweep's stream) -- what a Julia / C host gets; torch.distributed only carries the 128-byte id
+            from cfmmrouter_amd.dist import join_library_rccl
+            self.lib_rccl = join_library_rccl(self.be.ctx, None, torch.device("cuda", local_rank))
 
     def apply_options(self, be):
         for kv in self.args.opt:
@@ -80,7 +86,7 @@ class ShardBench:
             b_.ctx.sweep_dev(self.v_t.data_ptr(), self.out_t.data_ptr(), self.materialize)
             return
         self.be.ctx.sweep_dev(self.v_t.data_ptr(), self.out_t.data_ptr(), self.materialize)   # sharded context: already the global {Ψ, acc}
-        if self.use_dist and not self.fused_peer:
+        if self.use_dist and not self.fused_peer and not self.lib_rccl:
             dist.all_reduce(self.out_t)  # Ψ and the dual scalar: one small RCCL collective per evaluation
         self.steps_run += 1
 
@@ -169,11 +175,11 @@ class ShardBench:
         rank's shard that the ring's TOUCHED bytes are >= 2 x the cache (market_copies) makes every sweep read its pool
         state from HBM.  Every rank runs it (N > 1: the slowest rank's kernel time is reported)."""
         per_copy, copies = self.market_copies()
-        extra = [cr.DeviceBackend(self.n, self.batches, device=self.local_rank) for _ in range(copies - 1)]
+        extra = [cr.DeviceBackend(self.n, self.batches, device=self.local_rank) for _ in range(copies - (0 if self.lib_rccl else 1))]
         sharded = self.fused_peer
         if sharded:
             self.be.ctx.set_peers([], 0, 0, 0)
-        ring = [self.be] + extra
+        ring = ([] if self.lib_rccl else [self.be]) + extra    # (a context with a library RCCL communicator does not sweep locally)
         outs = [torch.zeros(self.n + 1, dtype=torch.float64, device="cuda") for _ in ring]
         for b_ in extra:
             b_.ctx.set_stream(self.stream.cuda_stream)
@@ -221,8 +227,16 @@ class ShardBench:
         got = self.out_t.clone()
         if self.fused_peer:
             self.be.ctx.set_peers([], 0, 0, 0)           # a LOCAL sweep for the reference
-        self.be.ctx.sweep_dev(self.v_t.data_ptr(), self.out_t.data_ptr(), self.materialize)
+        local = self.be
+        if self.lib_rccl:                                # the library's communicator is part of self.be: a plain context instead
+            local = cr.DeviceBackend(self.n, self.batches, device=self.local_rank)
+            local.ctx.set_stream(self.stream.cuda_stream)
+            self.apply_options(local)
+        local.ctx.sweep_dev(self.v_t.data_ptr(), self.out_t.data_ptr(), self.materialize)
         ref = self.out_t.clone()
+        if local is not self.be:
+            torch.cuda.synchronize()
+            local.close()
         dist.all_reduce(ref)
         torch.cuda.synchronize()
         if self.fused_peer:
@@ -236,7 +250,10 @@ class ShardBench:
         if self.fused_peer:
             return (f"pools x{self.world}, fold + one-shot xGMI peer all-reduce of n_tokens+1 f64 in one launch per step "
                     f"(buffers: library IPC export)")
-        return f"pools x{self.world}, RCCL all-reduce of n_tokens+1 f64 per step"
+        if self.lib_rccl:
+            return (f"pools x{self.world}, RCCL all-reduce of n_tokens+1 f64 per step INSIDE the library (cfmm_rccl_init_rank: "
+                    f"ncclAllReduce enqueued behind the fold on the sweep's stream)")
+        return f"pools x{self.world}, RCCL all-reduce of n_tokens+1 f64 per step (torch.distributed)"
 
     def close(self):
         if self.ring:

@@ -136,6 +136,9 @@ def lib():
     L.cfmm_peer_buffer_open.argtypes = [_ctx, C.c_char_p, C.POINTER(C.c_uint64)]
     L.cfmm_peer_buffer_close.argtypes = [_ctx, C.c_uint64]
     L.cfmm_peer_buffer_free.argtypes = [_ctx, C.c_uint64]
+    L.cfmm_rccl_unique_id.argtypes = [C.c_char_p]
+    L.cfmm_rccl_init_rank.argtypes = [_ctx, C.c_char_p, C.c_int32, C.c_int32]
+    L.cfmm_set_rccl_comm.argtypes = [_ctx, C.c_void_p]
     L.cfmm_segment_count.argtypes = [_ctx]
     L.cfmm_segment_count.restype = C.c_int32
     L.cfmm_segment_info.argtypes = [_ctx, C.c_int32, _i32p, _i64p, _i32p, _i32p]
@@ -369,6 +372,21 @@ class Context:
 
     def peer_buffer_free(self, ptr_: int):
         self._check(self._L.cfmm_peer_buffer_free(self._h, C.c_uint64(int(ptr_))))
+
+    # sharded operation through RCCL (include/cfmm_amd.h): rank 0 makes the id, every rank joins with it
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib().cfmm_rccl_unique_id(buf)
+        if rc != OK:
+            raise CFMMDeviceError(lib().cfmm_last_error(None).decode())
+        return buf.raw
+
+    def rccl_init_rank(self, uid: bytes, world: int, rank: int):
+        self._check(lib().cfmm_rccl_init_rank(self._h, uid, int(world), int(rank)))
+
+    def set_rccl_comm(self, comm_ptr):
+        self._check(lib().cfmm_set_rccl_comm(self._h, comm_ptr))
 
     def sweep_dev(self, d_v_ptr: int, d_out_ptr: int, materialize: bool):
         self._check(self._L.cfmm_sweep_dev(self._h, C.c_void_p(d_v_ptr), C.c_void_p(d_out_ptr),

@@ -174,6 +174,7 @@ void cfmm_ctx_destroy(cfmm_ctx* c)
     armed_cancel(c);
     if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    rccl_release(c);          // a communicator created by cfmm_rccl_init_rank goes with the context
     for (auto& s : c->segs) free_segment(s);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     free_trade_staging(c);

@@ -19,6 +19,7 @@ int cfmm_set_peers(cfmm_ctx* c, const uint64_t* peer_buffers, int32_t world, int
         c->peers.clear();
         return CFMM_OK;
     }
+    if (c->rccl_comm) return fail(c, CFMM_ERR_STATE, "an RCCL communicator is active on this context: one exchange at a time (cfmm_set_rccl_comm(ctx, NULL) first)");
     if (!peer_buffers || world < 1 || world > kMaxPeers || rank < 0 || rank >= world)
         return fail(c, CFMM_ERR_INVALID_ARG, "bad peer configuration");
     if (global_bins(c)) return fail(c, CFMM_ERR_UNSUPPORTED, "sharded operation is limited to n_tokens <= %d", kMaxLdsTokens);

@@ -316,7 +316,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     const bool gb = global_bins(c);
     const bool sharded = !c->peers.empty();   // fold + all-reduce over the peer mappings in one launch
     const unsigned long long* arm_word = arm_seq ? reinterpret_cast<const unsigned long long*>(c->d_arm + c->n_pad) : nullptr;
-    const bool host_out = want_host_out && !gb && (sharded || c->rows_total > 0) && c->d_stage != nullptr;
+    const bool rccl = c->rccl_comm != nullptr;   // the fold's {Ψ, acc} are this rank's part: all-reduced in-stream behind it
+    const bool host_out = want_host_out && !gb && !rccl && (sharded || c->rows_total > 0) && c->d_stage != nullptr;
     HostOut ho{nullptr, 0};
     if (host_out) {
         ++c->out_seq;
@@ -468,6 +469,10 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (bracket) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
+    if (rccl) {   // north_star: "RCCL all-reduce of Ψ and ∇g over xGMI per outer iteration" -- n + 1 doubles, on the same stream
+        rc = rccl_all_reduce_out(c, d_out);
+        if (rc != CFMM_OK) return rc;
+    }
     if (materialize) {
         c->have_trades = true;
         c->x_valid = false;
@@ -574,6 +579,8 @@ int take_host_out(cfmm_ctx* c)
             if (why & kFlagWindow)     // (a fast kernel met prices the host had vouched for: cannot happen unless v changed under the call)
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}: a price lies outside the window of the fast arithmetic "
                                                "(the price vector changed while the call ran?)");
+            if (c->rccl_comm)
+                return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d] after the RCCL all-reduce: a shard overflowed (on some rank)", j);
             if (!c->peers.empty())
                 return fail(c, CFMM_ERR_STATE, "non-finite {psi, acc}[%d]: the peer all-reduce timed out (a rank did not "
                                                "publish within CFMM_AMD_PEER_TIMEOUT_S) or a shard overflowed", j);
@@ -645,7 +652,7 @@ namespace {
 bool can_arm_single(cfmm_ctx* c)
 {
     if (c->opt_armed == 0 || !c->d_arm || c->opt_zero_copy == 0 || !c->d_stage || c->opt_host_flag == 0 ||
-        c->opt_time_kernels != 0 || c->n > 1024 || c->stream != c->own_stream || global_bins(c))
+        c->opt_time_kernels != 0 || c->n > 1024 || c->stream != c->own_stream || global_bins(c) || c->rccl_comm != nullptr)
         return false;
     return ensure_geometry(c) == CFMM_OK && c->rows_total > 0;
 }

@@ -10,6 +10,7 @@
 //   abi_route.cpp     route! in one call (L-BFGS-B + objectives), the bare solver
 //   abi_multi.cpp     single-process multi-device parents
 //   abi_peers.cpp     one process per GPU: peer buffers, cfmm_set_peers
+//   abi_rccl.cpp      one process per GPU: the all-reduce through RCCL (cfmm_set_rccl_comm, cfmm_rccl_init_rank)
 #pragma once
 
 #include "../../include/cfmm_amd.h"
@@ -149,6 +150,10 @@ struct cfmm_ctx {
     int peer_rank = 0;
     uint64_t peer_seq = 0;
     long long peer_timeout_ticks = 3000000000ll;   // 30 s of wall_clock64() at 100 MHz (CFMM_AMD_PEER_TIMEOUT_S)
+    // sharded operation through RCCL (cfmm_set_rccl_comm / cfmm_rccl_init_rank, abi_rccl.cpp): every sweep's fold is followed,
+    // in-stream, by ncclAllReduce(d_out, n + 1 doubles) -- same contract as `peers`, one exchange at a time
+    void* rccl_comm = nullptr;    // ncclComm_t
+    bool rccl_owned = false;      // created by cfmm_rccl_init_rank: destroyed with the context
     // pinned + device-mapped staging: [n] v in, [n+1] {Ψ, acc} out, padding to a 128-byte boundary, then the output
     // granules (16 per fold block = 2 per column, columns padded to a multiple of 8; see fold_finish)
     double* h_stage = nullptr;
@@ -276,5 +281,9 @@ int multi_get_trades_range(cfmm_ctx* c, int32_t seg, int64_t first, int64_t coun
 
 // abi_trades.cpp
 void free_trade_staging(cfmm_ctx* c);
+
+// abi_rccl.cpp
+int rccl_all_reduce_out(cfmm_ctx* c, double* d_out);
+void rccl_release(cfmm_ctx* c);
 
 } // namespace cfmm

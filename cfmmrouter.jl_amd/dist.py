@@ -98,6 +98,45 @@ def open_peer_buffers(ctx, group, device):
     return None
 
 
+def join_library_rccl(ctx, group, device):
+    """Puts `ctx` into sharded operation through the LIBRARY's RCCL entry points (include/cfmm_amd.h: cfmm_rccl_unique_id /
+    cfmm_rccl_init_rank): behind every sweep's fold the library itself enqueues ncclAllReduce(n_tokens + 1 doubles) on the
+    context's stream -- north_star's collective, with no torch in the evaluation loop (torch.distributed only carries the
+    128-byte id here, as any launcher's channel would).  Collective: True on ALL ranks or False on all ranks."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    vote_dev = device if dist.get_backend(group) == "nccl" else "cpu"
+
+    def all_ok(flag):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=vote_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return float(t.item()) == 1.0
+
+    uid = None
+    try:
+        uid = ctx.rccl_unique_id()          # every rank: proves RCCL resolves in this process BEFORE anybody enters the init
+    except Exception:
+        uid = None
+    if not all_ok(uid is not None):
+        return False
+    box = [uid]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ok = True
+    try:
+        ctx.rccl_init_rank(box[0], world, rank)     # collective inside RCCL: every rank got here (the vote above)
+    except Exception:
+        ok = False
+    if all_ok(ok):
+        return True
+    try:
+        ctx.set_rccl_comm(None)
+    except Exception:
+        pass
+    return False
+
+
 class PeerGuard:
     """Collective safety net of a router whose all-reduce lives inside the library (cfmm_set_peers).
 
@@ -304,6 +343,15 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
                     return r
                 backend.ctx.set_peers([], 0, 0, 0)
                 peers.close(collective=True)      # every rank is here (the vote was collective)
+        if torch.cuda.is_available() and n_tokens <= 8192 and os.environ.get("CFMM_AMD_NO_LIB_RCCL", "0") != "1":
+            # second choice: RCCL INSIDE the library (cfmm_rccl_init_rank): the fold launch is followed, in-stream, by
+            # ncclAllReduce of the n_tokens + 1 doubles -- route!'s one-call native solver works unchanged, launch-when-ready
+            with torch.cuda.device(dev):
+                joined = join_library_rccl(backend.ctx, group, torch.device("cuda", dev))
+            if joined:
+                r = Router(objective, local, n_tokens, _backend=backend)
+                r.collective = "RCCL all-reduce inside the library (cfmm_rccl_init_rank: ncclAllReduce behind every fold)"
+                return r
     r = Router(objective, local, n_tokens, _backend=ShardedBackend(backend, group))
     r.collective = "all-reduce through torch.distributed (RCCL)"
     return r

@@ -250,6 +250,28 @@ int cfmm_peer_buffer_open(cfmm_ctx* ctx, const unsigned char handle[CFMM_IPC_HAN
 int cfmm_peer_buffer_close(cfmm_ctx* ctx, uint64_t d_peer);
 int cfmm_peer_buffer_free(cfmm_ctx* ctx, uint64_t d_buf);
 
+/* ---- sharded runs through RCCL: north_star's "RCCL all-reduce of psi and grad g over xGMI per outer iteration" ---- */
+
+/* The same contract as cfmm_set_peers -- after the call EVERY sweep of the context (cfmm_find_arb, cfmm_eval, cfmm_route,
+ * cfmm_sweep_dev) returns the psi / acc of the WHOLE market while the context stores this rank's shard of the axis the
+ * reference threads over (src/router.jl:39) -- with the collective done by RCCL: behind every sweep's row fold the library
+ * enqueues ncclAllReduce(d_out, d_out, n_tokens + 1, ncclDouble, ncclSum, comm, stream) on the context's stream (one
+ * 4 KB collective per evaluation: latency, never link bandwidth).  No torch, no Python, no IPC handles: a Julia / C host
+ * shards a market in three calls --
+ *     rank 0:      cfmm_rccl_unique_id(id);          then broadcasts the 128 bytes with whatever its launcher has
+ *     every rank:  cfmm_rccl_init_rank(ctx, id, world, rank);   (collective: returns when all ranks have joined)
+ * -- or hands over a communicator it created itself (cfmm_set_rccl_comm: the caller keeps ownership; NULL switches the
+ * exchange off).  RCCL sums in its own (ring / tree) order: every rank receives the SAME bits (the lockstep L-BFGS-B of
+ * cfmm_route relies on it), but not the rank-ordered sum of cfmm_set_peers.  cfmm_set_peers (fold + exchange in ONE
+ * launch, +1.9 us per step instead of ~+9.5) stays the fast path; this is the portable one and the one the fast path is
+ * checked against (cfmmrouter.jl_amd/dist.py).  One exchange at a time per context (CFMM_ERR_STATE otherwise);
+ * evaluations are launched when their prices are ready (no pre-arming); n_tokens <= 8192.  RCCL is resolved at first use
+ * (the process's own RCCL if it has one loaded globally, else librccl.so.1): CFMM_ERR_UNSUPPORTED if there is none. */
+#define CFMM_RCCL_ID_BYTES 128
+int cfmm_rccl_unique_id(unsigned char id[CFMM_RCCL_ID_BYTES]);
+int cfmm_rccl_init_rank(cfmm_ctx* ctx, const unsigned char id[CFMM_RCCL_ID_BYTES], int32_t world, int32_t rank);
+int cfmm_set_rccl_comm(cfmm_ctx* ctx, void* nccl_comm /* ncclComm_t, or NULL */);
+
 /* ---- route! without an interpreter in the loop ----------------------- */
 
 #define CFMM_OBJ_LINEAR_NONNEGATIVE 0 /* LinearNonnegative(c)      src/objectives.jl:51-79 */

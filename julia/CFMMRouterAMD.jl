@@ -282,6 +282,33 @@ function set_option!(r::AMDRouter, key::AbstractString, value::Integer)
     return nothing
 end
 
+# Sharding over the GPUs of a node, one Julia process per GPU (Distributed.jl workers, MPI.jl ranks ...): north_star's
+# "RCCL all-reduce of Ψ and ∇g over xGMI per outer iteration" in three calls (include/cfmm_amd.h, sharded runs through RCCL).
+# Every rank builds its AMDRouter over ITS contiguous block of the cfmms vector (the axis of src/router.jl:39) on its own
+# device; rank 0 draws the id, the launcher's own channel carries the 128 bytes, every rank joins:
+#     id = rank == 0 ? rccl_unique_id() : nothing;  id = MPI.bcast(id, 0, comm)      # or remotecall_fetch / a file
+#     rccl_init_rank!(r, id, world, rank)            # collective
+# From then on find_arb!(r, v), eval_pools!, route!, route_native! return the Ψ / dual value of the WHOLE market on every
+# rank (bit-identical: the ranks' L-BFGS-B stays in lockstep); r.Δs / r.Λs are the local shard's trades.
+function rccl_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id check(C_NULL, ccall((:cfmm_rccl_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+
+function rccl_init_rank!(r::AMDRouter, id::Vector{UInt8}, world::Integer, rank::Integer)
+    length(id) == 128 || throw(ArgumentError("the id of rccl_unique_id() has 128 bytes"))
+    GC.@preserve id check(r.ctx, ccall((:cfmm_rccl_init_rank, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32),
+                                       r.ctx, id, Int32(world), Int32(rank)))
+    return nothing
+end
+
+# a communicator the host created itself (RCCL.jl / a C launcher); C_NULL switches the exchange off
+function set_rccl_comm!(r::AMDRouter, comm::Ptr{Cvoid})
+    check(r.ctx, ccall((:cfmm_set_rccl_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.ctx, comm))
+    return nothing
+end
+
 # netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125
 function netflows!(ψ, r::AMDRouter)
     ψ .= r.Ψ

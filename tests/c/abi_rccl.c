@@ -1,0 +1,114 @@
+/* Plain-C client of the RCCL entry points of libcfmm_amd.so (include/cfmm_amd.h): north_star's "RCCL all-reduce of psi and
+ * grad g over xGMI per outer iteration" reached from a non-Python host in three calls.  usage: abi_rccl [world]
+ *   world = 1 (default): one process, one rank -- the communicator path end to end on one GPU (run by tests/test_c_abi_gpu.py);
+ *   world = N > 1:       forks N - 1 more processes, rank r on GPU r, the 128-byte id handed over through a pipe -- what a
+ *                        launcher (MPI, a Julia Distributed worker pool) does with it; every rank holds 1/N of the market and
+ *                        must return the psi of the WHOLE market (needs N GPUs: the driver's node, not the 1-GPU box).
+ * Market: 40 000 ProductTwoCoin pools over 16 tokens from a fixed LCG; checked against the unsharded sweep of the same pools. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "cfmm_amd.h"
+
+#define M 40000
+#define N 16
+
+static double R[2 * M], g[M], v[N];
+static int32_t Ai[2 * M];
+
+static unsigned long long lcg_state = 88172645463325252ull;
+static double u01(void)
+{
+    lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(lcg_state >> 11) / 9007199254740992.0;
+}
+
+#define CHECK(call)                                                                     \
+    do {                                                                                \
+        int rc_ = (call);                                                               \
+        if (rc_ != CFMM_OK) {                                                           \
+            fprintf(stderr, "rank %d: %s -> %d: %s\n", rank, #call, rc_, cfmm_last_error(ctx)); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+static int run_rank(int rank, int world, const unsigned char* id, const double* psi_ref, double acc_ref)
+{
+    cfmm_ctx* ctx = NULL;
+    if (cfmm_ctx_create(world > 1 ? rank : 0, N, &ctx) != CFMM_OK) {
+        fprintf(stderr, "rank %d: cfmm_ctx_create: %s\n", rank, cfmm_last_error(NULL));
+        return 2;
+    }
+    const long lo = (long)M * rank / world, hi = (long)M * (rank + 1) / world;     /* contiguous shard (src/router.jl:39's axis) */
+    CHECK(cfmm_pools_add_product(ctx, hi - lo, R + 2 * lo, g + lo, Ai + 2 * lo));
+    CHECK(cfmm_rccl_init_rank(ctx, id, world, rank));                               /* call 2 of 3 (call 1: the id, below) */
+    double psi[N], acc;
+    CHECK(cfmm_eval(ctx, v, psi, &acc));                                            /* global psi / acc on every rank */
+    double err = fabs(acc - acc_ref) / fmax(fabs(acc_ref), 1.0), scale = 0.0;
+    for (int j = 0; j < N; ++j) scale = fmax(scale, fabs(psi_ref[j]));
+    for (int j = 0; j < N; ++j) err = fmax(err, fabs(psi[j] - psi_ref[j]) / scale);
+    printf("rank %d/%d: pools [%ld, %ld)  psi[0]=%.17g acc=%.17g  rel err vs unsharded %.3e\n", rank, world, lo, hi, psi[0], acc, err);
+    /* route! on the sharded context: every rank runs the same L-BFGS-B on identical {psi, acc} */
+    double c[N], vout[N], psi_route[N];
+    for (int j = 0; j < N; ++j) c[j] = 0.5 + 0.05 * j;
+    cfmm_route_info info;
+    CHECK(cfmm_route(ctx, CFMM_OBJ_LINEAR_NONNEGATIVE, c, 0, NULL, 5, 1e1, 1e-5, 15000, 15000, vout, psi_route, &info));
+    double neg = 0.0;
+    for (int j = 0; j < N; ++j) neg = fmin(neg, psi_route[j] / scale);
+    printf("rank %d/%d: route! %d evaluations, status %d, min psi/scale %.2e\n", rank, world, info.evaluations, info.status, neg);
+    CHECK(cfmm_set_rccl_comm(ctx, NULL));                                           /* exchange off: the shard alone again */
+    cfmm_ctx_destroy(ctx);
+    return (err <= 1e-12 && neg >= -1e-6 && info.status <= 1) ? 0 : 3;
+}
+
+int main(int argc, char** argv)
+{
+    const int world = argc > 1 ? atoi(argv[1]) : 1;
+    for (long i = 0; i < M; ++i) {
+        R[2 * i] = 1000.0 * (0.05 + u01());
+        R[2 * i + 1] = 1000.0 * (0.05 + u01());
+        g[i] = u01() < 0.5 ? 0.997 : 1.0;
+        const int a = (int)(u01() * N) % N, b = (a + 1 + (int)(u01() * (N - 1)) % (N - 1)) % N;
+        Ai[2 * i] = a;
+        Ai[2 * i + 1] = b;
+    }
+    for (int j = 0; j < N; ++j) v[j] = exp(0.3 * sin(1.7 * j));
+    /* the reference: the whole market on one context, no exchange */
+    double psi_ref[N], acc_ref;
+    {
+        cfmm_ctx* ctx = NULL;
+        int rank = -1;
+        if (cfmm_ctx_create(0, N, &ctx) != CFMM_OK) {
+            fprintf(stderr, "cfmm_ctx_create: %s\n", cfmm_last_error(NULL));
+            return 2;
+        }
+        CHECK(cfmm_pools_add_product(ctx, M, R, g, Ai));
+        CHECK(cfmm_eval(ctx, v, psi_ref, &acc_ref));
+        cfmm_ctx_destroy(ctx);
+    }
+    unsigned char id[CFMM_RCCL_ID_BYTES];
+    {
+        cfmm_ctx* ctx = NULL;
+        int rank = 0;
+        CHECK(cfmm_rccl_unique_id(id));                                             /* call 1 of 3: rank 0 */
+    }
+    if (world <= 1) return run_rank(0, 1, id, psi_ref, acc_ref);
+    /* call "broadcast": here a fork -- the children inherit the id (a real launcher sends the 128 bytes) */
+    pid_t kids[64];
+    for (int r = 1; r < world && r < 64; ++r) {
+        kids[r] = fork();
+        if (kids[r] == 0) _exit(run_rank(r, world, id, psi_ref, acc_ref));
+    }
+    int rc = run_rank(0, world, id, psi_ref, acc_ref);
+    for (int r = 1; r < world && r < 64; ++r) {
+        int st = 0;
+        waitpid(kids[r], &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 4;
+    }
+    printf("%s\n", rc == 0 ? "RCCL_ABI_OK" : "RCCL_ABI_FAILED");
+    return rc;
+}

@@ -143,13 +143,8 @@ def test_nan_prices_propagate_through_device_pointer_sweeps():
         v[5] = np.nan
         vt = torch.from_numpy(v).cuda()
         out = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
-        be.ctx.sweep_dev(vt.data_ptr(), out.data_ptr(), True)
-        torch.cuda.synchronize()
-        assert np.all(np.isnan(out.cpu().numpy()))         # the fast kernels refuse a NaN price: everything NaN ...
-        with pytest.raises(RuntimeError, match="outside"):
-            be.ctx.sweep_dev(vt.data_ptr(), out.data_ptr(), True)    # ... reported once ...
-        be.ctx.sweep_dev(vt.data_ptr(), out.data_ptr(), True)        # ... and the full-range kernels propagate it per pool
-        torch.cuda.synchronize()
+        be.ctx.sweep_dev(vt.data_ptr(), out.data_ptr(), True)        # round 5: the very first sweep propagates it per pool (the
+        torch.cuda.synchronize()                                     # launch carries both arithmetics; round 4 refused it once)
         o = out.cpu().numpy()
         assert np.isnan(o[5]) and np.isnan(o[n])
         D, L = be.trades()

@@ -19,6 +19,7 @@ C2J = {   # C parameter type (const and spaces stripped) -> acceptable Julia cca
     "int32_t*": {"Ptr{Int32}", "Ref{Int32}"},
     "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
     "char*": {"Cstring", "Ptr{UInt8}"},
+    "unsignedchar*": {"Ptr{UInt8}"},
     "void*": {"Ptr{Cvoid}"},
     "void": {"Cvoid"},
     "cfmm_route_info*": {"Ref{RouteInfo}", "Ptr{RouteInfo}"},
@@ -36,6 +37,7 @@ def c_declarations():
         plist = []
         for p in [q.strip() for q in params.replace("\n", " ").split(",") if q.strip() and q.strip() != "void"]:
             p = re.sub(r"\bconst\b", "", p).strip()
+            p = re.sub(r"^(.*?)(\w+)\s*\[[^\]]*\]$", r"\1* \2", p)      # `unsigned char id[N]` is `unsigned char* id`
             mm = re.match(r"^(.*?)(\w+)?$", p)            # strip the parameter name
             ty = mm.group(1).strip() if mm.group(1).strip() else p
             ty = ty.replace(" ", "")
