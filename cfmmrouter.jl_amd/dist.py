@@ -313,7 +313,11 @@ def ShardedRouter(objective, cfmms, n_tokens, rank=None, world=None, device=None
     world = dist.get_world_size(group) if world is None else world
     if not isinstance(cfmms, PoolBatch):
         cfmms = list(cfmms)
-    batches, _ = _segments_of(cfmms)
+    batches, _, host = _segments_of(cfmms)
+    if host:
+        from ._lib import ArgumentError
+        raise ArgumentError("ShardedRouter: pools without a device kernel (host-evaluated CFMM subclasses) are not sharded; "
+                            "use Router on one GPU")
     local = batches if already_sharded else shard_batches(batches, rank, world)
     if _local_backend_factory is not None:
         backend = _local_backend_factory(n_tokens, local)

@@ -69,13 +69,16 @@ class DeviceBackend:
 def _segments_of(cfmms):
     """Pack a pool container into homogeneous batches.
 
-    Returns (batches, order) where `order[k]` is the router index of the k-th packed pool
-    (None when packing preserved the router order)."""
+    Returns (batches, order, host) where `order[k]` is the router index of the k-th packed pool (None when packing
+    preserved the router order) and `host` lists the router indices of pools whose TYPE has no device kernel -- any
+    other CFMM subclass with its own `find_arb_(Δ, Λ, v)` method, the reference's plugin seam (src/cfmms.jl:35,56:
+    `find_arb!(Δ, Λ, cfmm::CFMM, v)` is dispatched on the pool's type, so a user's own CFMM subtype enters a Router
+    by defining that one method).  They are evaluated on the host every evaluation (HostSegment)."""
     if isinstance(cfmms, PoolBatch):
-        return [cfmms], None
+        return [cfmms], None, []
     cfmms = list(cfmms)
     if cfmms and all(isinstance(c, PoolBatch) for c in cfmms):
-        return cfmms, None
+        return cfmms, None, []
     for c in cfmms:
         if not isinstance(c, CFMM):
             raise ArgumentError("cfmms must hold CFMM objects or PoolBatch containers")
@@ -85,10 +88,76 @@ def _segments_of(cfmms):
         if idx:
             batches.append(PoolBatch.from_pools(kind, [cfmms[i] for i in idx]))
             order.extend(idx)
+    host = [i for i, c in enumerate(cfmms) if c.kind not in (KIND_PRODUCT, KIND_GEOMEAN, KIND_UNIV3)]
+    for i in host:
+        if not callable(getattr(cfmms[i], "find_arb_", None)) or not hasattr(cfmms[i], "Ai"):
+            raise ArgumentError(f"cfmms[{i}] ({type(cfmms[i]).__name__}): a pool type without a device kernel needs its own "
+                                f"find_arb_(Δ, Λ, v) method and an `Ai` field (src/cfmms.jl:35,56)")
     order = np.array(order, dtype=np.int64)
-    if np.array_equal(order, np.arange(len(cfmms))):
+    if not host and np.array_equal(order, np.arange(len(cfmms))):
         order = None
-    return batches, order
+    return batches, order, host
+
+
+class HostSegment:
+    """Pools whose type has no device kernel: the CALLER's own `find_arb_(Δ, Λ, v_local)` (Julia: the user's
+    `find_arb!(Δ, Λ, cfmm, v)` method, src/cfmms.jl:35) runs on the host at every evaluation, exactly as
+    `find_arb!(r::Router, v)` would call it (src/router.jl:40: `find_arb!(r.Δs[i], r.Λs[i], r.cfmms[i], v[r.cfmms[i].Ai])`),
+    and their part of Ψ (src/router.jl:98-100, :114-115) and of the dual scalar (:82) is added to what the device returns.
+    Any number of coins per pool (`len(pool.Ai)`)."""
+
+    def __init__(self, pools, n_tokens):
+        self.pools = list(pools)
+        self.n_tokens = int(n_tokens)
+        self.Ai0 = []
+        for c in self.pools:
+            ai = np.asarray(c.Ai, dtype=np.int64).reshape(-1) - 1
+            if ai.size == 0 or np.any(ai < 0) or np.any(ai >= n_tokens):
+                raise ArgumentError(f"token index out of range 1:{n_tokens}")
+            self.Ai0.append(ai)
+        self.Δs = [np.zeros(ai.size) for ai in self.Ai0]      # zerotrade(c), src/router.jl:23-26
+        self.Λs = [np.zeros(ai.size) for ai in self.Ai0]
+
+    def sweep(self, v):
+        psi, acc = np.zeros(self.n_tokens), 0.0
+        for c, ai, D, L in zip(self.pools, self.Ai0, self.Δs, self.Λs):
+            vl = v[ai]                                   # v[r.cfmms[i].Ai]
+            c.find_arb_(D, L, vl)                        # the user's method: overwrites Δ, Λ
+            acc += float(np.dot(L, vl) - np.dot(D, vl))  # src/router.jl:82
+            np.add.at(psi, ai, L - D)                    # src/router.jl:99
+        return psi, acc
+
+
+class MixedBackend:
+    """A device (or any other) backend plus a HostSegment: one evaluation = the backend's sweep + the host pools' own
+    find_arb_, their Ψ and dual parts summed -- what L-BFGS-B sees is the dual of the WHOLE router."""
+
+    def __init__(self, inner, host: HostSegment):
+        self.inner, self.host = inner, host
+        self.n_tokens = host.n_tokens
+
+    def _add(self, res, v):
+        psi, acc = res
+        ph, ah = self.host.sweep(np.asarray(v, dtype=np.float64))
+        return psi + ph, acc + ah
+
+    def eval(self, v):
+        return self._add(self.inner.eval(v), v)
+
+    def find_arb(self, v):
+        return self._add(self.inner.find_arb(v), v)
+
+    def trades(self, out=None):
+        return self.inner.trades() if out is None else self.inner.trades(out)
+
+    def reload(self, batches):
+        self.inner.reload(batches)
+
+    ctx = property(lambda self: self.inner.ctx)     # library options / introspection of the device half
+
+    def close(self):
+        if hasattr(self.inner, "close"):
+            self.inner.close()
 
 
 class _PoolView:
@@ -124,14 +193,19 @@ class Router:
         self.n_tokens = int(n_tokens)
         if not isinstance(cfmms, PoolBatch):
             cfmms = list(cfmms)
-        batches, self._order = _segments_of(cfmms)
+        batches, self._order, host = _segments_of(cfmms)
         self._batches = batches
         from_batches = isinstance(cfmms, PoolBatch) or (
             len(batches) > 0 and not isinstance(cfmms, PoolBatch) and all(isinstance(c, PoolBatch) for c in cfmms))
         self.cfmms = _PoolView(batches) if from_batches else list(cfmms)
-        self._m = sum(len(b) for b in batches)
+        self._m = sum(len(b) for b in batches)       # pools with a device kernel
         self.v = np.zeros(self.n_tokens)  # :33
         self._backend = _backend if _backend is not None else DeviceBackend(self.n_tokens, batches, device)
+        # the plugin seam: pools of any other CFMM subclass are evaluated by their own find_arb_ on the host
+        self._host = HostSegment([cfmms[i] for i in host], self.n_tokens) if host else None
+        self._host_idx = list(host)
+        if self._host is not None:
+            self._backend = MixedBackend(self._backend, self._host)
         self._psi = np.zeros(self.n_tokens)
         self._acc = 0.0
         self._Δs = np.zeros((self._m, 2))  # zerotrade per pool, :23-26
@@ -140,10 +214,13 @@ class Router:
         self.n_sweeps = 0
         self.info = None
 
-    # r.Δs / r.Λs: [m, 2] arrays in router order (rows are the reference's per-pool vectors)
+    # r.Δs / r.Λs: [m, 2] arrays in router order (rows are the reference's per-pool vectors); routers with host-evaluated
+    # pools: a list of per-pool vectors in router order (the reference's Vector{Vector}), host pools' vectors included
     def _fetch(self):
         if self._trades_stale:
-            if self._order is not None:
+            if self._host is not None:        # packed order on the device; _rows() maps router index -> row
+                self._Δs, self._Λs = self._backend.trades()
+            elif self._order is not None:
                 D, Lm = self._backend.trades()
                 self._Δs[self._order] = D
                 self._Λs[self._order] = Lm
@@ -154,15 +231,23 @@ class Router:
                     self._Δs, self._Λs = self._backend.trades()
             self._trades_stale = False
 
+    def _rows(self, dev, host):
+        out = [None] * (self._m + len(self._host_idx))
+        for k, i in enumerate(self._order if self._order is not None else range(self._m)):
+            out[int(i)] = dev[k]
+        for j, i in enumerate(self._host_idx):
+            out[i] = host[j]
+        return out
+
     @property
     def Δs(self):
         self._fetch()
-        return self._Δs
+        return self._Δs if self._host is None else self._rows(self._Δs, self._host.Δs)
 
     @property
     def Λs(self):
         self._fetch()
-        return self._Λs
+        return self._Λs if self._host is None else self._rows(self._Λs, self._host.Λs)
 
     Deltas = Δs
     Lambdas = Λs
@@ -438,6 +523,16 @@ def update_reserves_(r: Router, sync_host=True):
     consumed.  sync_host=True (default) also refreshes the host mirror (`r.cfmms[i].R`, batch.R,
     batch.current_price: 16 / 8 bytes per pool device-to-host); sequential routing that never reads
     them can pass sync_host=False and moves no per-pool data at all."""
+    if r._host is not None:
+        # host-evaluated pools: the pool type's own update_reserves_(Δ, Λ, v) -- the per-pool method the reference's
+        # router calls (src/router.jl:129: update_reserves!(c, Δ, Λ, r.v[c.Ai])) -- then zero trades
+        for c in r._host.pools:
+            if not callable(getattr(c, "update_reserves_", None)):
+                raise ArgumentError(f"{type(c).__name__} has no update_reserves_(Δ, Λ, v) method (src/router.jl:129)")
+        for c, ai, D, L in zip(r._host.pools, r._host.Ai0, r._host.Δs, r._host.Λs):
+            c.update_reserves_(D, L, r.v[ai])
+            D[:] = 0.0
+            L[:] = 0.0
     ctx = getattr(r._backend, "ctx", None)
     if ctx is None:   # test-injected / sharded backends: host-side update of the two-coin families
         return _update_reserves_host(r)

@@ -45,6 +45,7 @@ mutable struct AMDRouter{O,T}
     order::Vector{Int}          # packed position -> index into cfmms (pools are grouped by family)
     Ψ::Vector{T}
     acc::Base.RefValue{T}
+    host::Vector{Int}           # indices of pools whose TYPE has no device kernel: evaluated by their own find_arb! on the host
 end
 
 # Router(objective, cfmms, n_tokens) -- src/router.jl:18-36
@@ -98,19 +99,39 @@ function AMDRouter(objective::O, cfmms::Vector{C}, n_tokens; device=0) where {O<
             ctx, length(idx), cp, γ, Ai, off, ticks, liq))
         append!(order, idx)
     end
-    length(order) == length(cfmms) || throw(ArgumentError("unsupported CFMM type in cfmms"))
-    Δs = [zeros(2) for _ in cfmms]; Λs = [zeros(2) for _ in cfmms]    # zerotrade, src/router.jl:23-26
+    # The reference's plugin seam (src/cfmms.jl:35,56; src/router.jl:40): a Router takes ANY CFMM{T} subtype that has a
+    # find_arb!(Δ, Λ, cfmm, v) method.  Pools of such a type are not uploaded: every evaluation calls the user's own method
+    # on the host and adds its (Λ − Δ) and dual term to what the device returns (host_part! below).
+    host = setdiff(1:length(cfmms), order)
+    for i in host
+        hasmethod(CFMMRouter.find_arb!, Tuple{Vector{Float64},Vector{Float64},typeof(cfmms[i]),Vector{Float64}}) ||
+            throw(ArgumentError("cfmms[$i]::$(typeof(cfmms[i])) has no device kernel and no find_arb!(Δ, Λ, cfmm, v) method"))
+    end
+    Δs = [CFMMRouter.zerotrade(c) for c in cfmms]; Λs = [CFMMRouter.zerotrade(c) for c in cfmms]    # src/router.jl:23-26
     r = AMDRouter{O,Float64}(objective, convert(Vector{CFMM{Float64}}, cfmms), Δs, Λs, zeros(n_tokens), ctx, order,
-                             zeros(n_tokens), Ref(0.0))
+                             zeros(n_tokens), Ref(0.0), collect(host))
     finalizer(x -> ccall((:cfmm_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ctx), r)
     return r
+end
+
+# Pools without a device kernel: the user's find_arb! per pool (src/router.jl:40), their part of Ψ (src/router.jl:98-100)
+# and of the dual scalar (:82) added to the device's
+function host_part!(r::AMDRouter, v)
+    for i in r.host
+        c = r.cfmms[i]
+        vl = v[c.Ai]
+        CFMMRouter.find_arb!(r.Δs[i], r.Λs[i], c, vl)
+        r.acc[] += sum(r.Λs[i] .* vl) - sum(r.Δs[i] .* vl)
+        r.Ψ[c.Ai] .+= r.Λs[i] .- r.Δs[i]
+    end
+    return nothing
 end
 
 # find_arb!(r::Router, v) -- src/router.jl:38-42: materialising device sweep, then r.Δs/r.Λs are filled
 function find_arb!(r::AMDRouter, v)
     vv = Vector{Float64}(v)
     GC.@preserve vv check(r.ctx, ccall((:cfmm_find_arb, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), r.ctx, vv))
-    m = length(r.cfmms)
+    m = length(r.order)
     D = Matrix{Float64}(undef, 2, m); L = Matrix{Float64}(undef, 2, m)
     GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
     for (k, i) in enumerate(r.order)
@@ -118,6 +139,7 @@ function find_arb!(r::AMDRouter, v)
     end
     check(r.ctx, ccall((:cfmm_netflows, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), r.ctx, r.Ψ))
     check(r.ctx, ccall((:cfmm_dual_value, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), r.ctx, r.acc))
+    host_part!(r, vv)
     return nothing
 end
 
@@ -126,6 +148,7 @@ function eval_pools!(r::AMDRouter, v)
     vv = Vector{Float64}(v)
     GC.@preserve vv check(r.ctx, ccall((:cfmm_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
                                        r.ctx, vv, r.Ψ, r.acc))
+    host_part!(r, vv)
     return nothing
 end
 
@@ -171,6 +194,9 @@ end
 # find_arb!/route!; UniV3 pools move to the price the arbitrage left them at.  The host-side pool objects
 # are refreshed from the device (16 bytes per two-coin pool, 8 per UniV3 pool); `sync=false` skips that.
 function update_reserves!(r::AMDRouter; sync::Bool=true)
+    for i in r.host      # host-evaluated pool types: their own per-pool method, as src/router.jl:129 calls it
+        CFMMRouter.update_reserves!(r.cfmms[i], r.Δs[i], r.Λs[i], r.v[r.cfmms[i].Ai])
+    end
     check(r.ctx, ccall((:cfmm_update_reserves, LIB), Cint, (Ptr{Cvoid},), r.ctx))
     if sync
         seg, pos = Int32(0), 0
@@ -212,6 +238,7 @@ struct RouteInfo
 end
 
 function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxfun=15_000, maxiter=15_000)
+    isempty(r.host) || throw(ArgumentError("route_native! runs inside the library: routers with host-evaluated pool types use route!"))
     obj = r.objective
     kind, vec, idx = if obj isa CFMMRouter.LinearNonnegative
         (Int32(0), Vector{Float64}(obj.c), Int32(0))
@@ -231,7 +258,7 @@ function route_native!(r::AMDRouter; v=nothing, m=5, factr=1e1, pgtol=1e-5, maxf
         vout, r.Ψ, info))
     r.v .= vout
     # trades were materialised at v* by the same call
-    mm = length(r.cfmms)
+    mm = length(r.order)
     D = Matrix{Float64}(undef, 2, mm); L = Matrix{Float64}(undef, 2, mm)
     GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
     for (k, i) in enumerate(r.order)
@@ -252,6 +279,7 @@ struct PolishInfo
 end
 
 function polish!(r::AMDRouter; max_iters=8, rel_step=1e-7)
+    isempty(r.host) || throw(ArgumentError("polish! runs inside the library: not available with host-evaluated pool types"))
     obj = r.objective
     kind, vec, idx = if obj isa CFMMRouter.LinearNonnegative
         (Int32(0), Vector{Float64}(obj.c), Int32(0))
@@ -266,7 +294,7 @@ function polish!(r::AMDRouter; max_iters=8, rel_step=1e-7)
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ref{PolishInfo}),
         r.ctx, kind, vec, idx, vio, max_iters, rel_step, r.Ψ, info))
     r.v .= vio
-    mm = length(r.cfmms)
+    mm = length(r.order)
     D = Matrix{Float64}(undef, 2, mm); L = Matrix{Float64}(undef, 2, mm)
     GC.@preserve D L check(r.ctx, ccall((:cfmm_get_trades, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), r.ctx, D, L))
     for (k, i) in enumerate(r.order)

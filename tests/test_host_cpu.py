@@ -155,7 +155,7 @@ def check_dual_feasibility(r, TOL=1e-4):
 def oracle_router(objective, pools, n):
     probe = cr.Router.__new__(cr.Router)  # pack first to learn the batches the backend needs
     from cfmmrouter_amd.router import _segments_of
-    batches, _ = _segments_of(pools if isinstance(pools, cr.PoolBatch) else list(pools))
+    batches, _, _ = _segments_of(pools if isinstance(pools, cr.PoolBatch) else list(pools))
     return cr.Router(objective, pools, n, _backend=OracleBackend(n, batches))
 
 
