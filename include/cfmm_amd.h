@@ -299,6 +299,30 @@ int cfmm_route(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_ve
                const double* v0, int32_t m, double factr, double pgtol, int32_t maxfun, int32_t maxiter,
                double* v_out, double* psi_out, cfmm_route_info* info);
 
+/* The solver alone on a caller-supplied objective (used by the CPU tests to compare it with
+ * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g.
+ * boxed_from_nbd != 0: like the Fortran code, treat the problem as "boxed" (unit first step) when
+ * every nbd[i] == 2 even if a bound is infinite -- what the reference's call does
+ * (src/router.jl:67-70) and what cfmm_route uses; 0: infinite bounds are no bounds (SciPy). */
+typedef double (*cfmm_fg_callback)(void* user, const double* x, double* g);
+int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
+                         cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
+                         int32_t maxiter, int32_t boxed_from_nbd, cfmm_route_info* info);
+
+/* Number of segments and their description (kind, pool count, launch geometry). */
+int32_t cfmm_segment_count(const cfmm_ctx* ctx);
+int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* block,
+                      int32_t* grid);
+
+/* ==== EXPERIMENTAL -- beyond the reference's verbs ====================================================================
+ * Everything ABOVE this line is the drop-in surface: the reference's own verbs (Router, find_arb!, route!, netflows,
+ * update_reserves!, the objectives) and what sharding them needs.  What follows is NOT in CFMMRouter.jl, may change, and
+ * is not needed to replace the reference's path:
+ *   - cfmm_polish (below),
+ *   - the option "stop_in_noise" (cfmm_set_option; default 0 = the stopping rules of L-BFGS-B 3.0),
+ *   - the test / A-B hooks "debug_stall_ms", "debug_dev_trust".
+ * ====================================================================================================================== */
+
 /* Tighten a route!'s result beyond what L-BFGS-B's stopping rules can (NOT part of the reference: its route! ends where
  * LBFGSB.jl ends, src/router.jl:105-107).  L-BFGS-B's line search compares dual VALUES, whose rounding noise -- a sum
  * over all pools -- hides decreases below ~1e-15 relative; on interior optima that leaves a stationarity residual of
@@ -321,21 +345,6 @@ typedef struct cfmm_polish_info {
 } cfmm_polish_info;
 int cfmm_polish(cfmm_ctx* ctx, int32_t objective_kind, const double* objective_vec, int32_t objective_index,
                 double* v, int32_t max_iters, double rel_step, double* psi_out, cfmm_polish_info* info);
-
-/* The solver alone on a caller-supplied objective (used by the CPU tests to compare it with
- * SciPy's L-BFGS-B).  nbd[i]: 0 free, 1 lower, 2 both, 3 upper.  fg returns f and fills g.
- * boxed_from_nbd != 0: like the Fortran code, treat the problem as "boxed" (unit first step) when
- * every nbd[i] == 2 even if a bound is infinite -- what the reference's call does
- * (src/router.jl:67-70) and what cfmm_route uses; 0: infinite bounds are no bounds (SciPy). */
-typedef double (*cfmm_fg_callback)(void* user, const double* x, double* g);
-int cfmm_lbfgsb_minimize(int32_t n, double* x, const double* lower, const double* upper, const int32_t* nbd,
-                         cfmm_fg_callback fg, void* user, int32_t m, double factr, double pgtol, int32_t maxfun,
-                         int32_t maxiter, int32_t boxed_from_nbd, cfmm_route_info* info);
-
-/* Number of segments and their description (kind, pool count, launch geometry). */
-int32_t cfmm_segment_count(const cfmm_ctx* ctx);
-int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* m, int32_t* block,
-                      int32_t* grid);
 
 #ifdef __cplusplus
 }

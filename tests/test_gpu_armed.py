@@ -186,3 +186,65 @@ def test_stop_in_noise_is_an_option_and_off_by_default():
         assert np.max(np.abs(psi1 - psi0)) <= 1e-6 * np.max(np.abs(psi0))
     finally:
         be.close()
+
+
+# ---- fault injection, one test per transition of the hand-over protocols that one GPU can reach ----------
+
+def test_prices_outside_the_fast_window_cancel_the_waiting_launch():
+    """Transition "armed launch waiting -> prices turn out to be outside [2^-150, 2^150]": the waiting launch runs the fast
+    arithmetic (its kernel was chosen before the prices existed), so armed_eval cancels it and evaluates launch-when-ready
+    on the full-range kernels; the rest of the route runs unarmed.  Same bits as armed = 0, and the context is clean."""
+    n = 32
+    batches = [synth.product_pools(60_000, n, seed=21)]
+    c = synth.linear_prices(n, seed=22) * 2.0 ** 170          # lower_limit = c + 1e-8: every price of the route is outside
+    res = [run_route(batches, n, OBJ_LINEAR_NONNEGATIVE, c, 0, armed, v0=c * 1.5) for armed in (1, 0)]
+    for a, b in zip(res[0], res[1]):
+        if isinstance(a, dict):
+            assert a["evaluations"] == b["evaluations"] and a["status"] == b["status"]
+        else:
+            np.testing.assert_array_equal(a, b)
+    assert np.all(np.isfinite(res[0][1]))
+
+
+def test_a_peer_that_never_publishes_times_out_and_the_context_recovers():
+    """Transition "fold + gather waiting for a peer's granules -> CFMM_AMD_PEER_TIMEOUT_S elapses": world = 2 with a second
+    buffer nobody ever writes.  The gather gives up after the time limit, {psi, acc} come back NaN, the host call fails
+    with CFMM_ERR_STATE naming the peer wait (never a number), and after cfmm_set_peers(world = 0) the same context
+    evaluates its shard as if nothing had happened."""
+    import os
+    import time
+    n = 24
+    batches = [synth.product_pools(40_000, n, seed=51)]
+    v = synth.sweep_prices(n, seed=52)
+    old = os.environ.get("CFMM_AMD_PEER_TIMEOUT_S")
+    os.environ["CFMM_AMD_PEER_TIMEOUT_S"] = "0.3"
+    be = cr.DeviceBackend(n, batches)
+    mine = ghost = None
+    try:
+        psi0, acc0 = be.eval(v)
+        mine, _ = be.ctx.peer_buffer_alloc()
+        ghost, _ = be.ctx.peer_buffer_alloc()                 # "rank 1": zero-initialised, never published to
+        be.ctx.set_peers([mine, ghost], 2, 0, 0)
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="peer"):
+            be.eval(v)
+        assert 0.25 <= time.perf_counter() - t0 <= 5.0        # bounded by the time limit, not by the 30 s default
+        with pytest.raises(RuntimeError, match="peer"):       # a route on the same context: fails, leaves no launch behind
+            be.ctx.route(OBJ_LINEAR_NONNEGATIVE, synth.linear_prices(n, seed=53), 0, v0=np.ones(n))
+        be.ctx.set_peers([], 0, 0, 0)
+        psi1, acc1 = be.eval(v)
+        np.testing.assert_allclose(psi1, psi0, rtol=0, atol=1e-14 * np.max(np.abs(psi0)))
+        v_r, psi_r, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, synth.linear_prices(n, seed=53), 0, v0=np.ones(n))
+        assert np.all(np.isfinite(psi_r)) and info["status"] in (0, 1)
+    finally:
+        try:
+            be.ctx.set_peers([], 0, 0, 0)
+            for p_ in (mine, ghost):
+                if p_ is not None:
+                    be.ctx.peer_buffer_free(p_)
+        finally:
+            be.close()
+            if old is None:
+                os.environ.pop("CFMM_AMD_PEER_TIMEOUT_S", None)
+            else:
+                os.environ["CFMM_AMD_PEER_TIMEOUT_S"] = old
