@@ -31,11 +31,14 @@ single = cr.Router(obj, market, n, device=lr)
 v = synth.sweep_prices(n, seed=3)
 cr.find_arb_(single, v)
 psi_fixed, D_fixed, L_fixed = cr.netflows(single).copy(), single.Δs.copy(), single.Λs.copy()
-for name, no_peer in (("peer", "0"), ("rccl", "1")):
+# the three collectives of ShardedRouter, in its order of preference: peer exchange inside the fold launch, RCCL inside the
+# library (cfmm_rccl_init_rank: ncclAllReduce behind every fold), torch.distributed
+for name, no_peer, no_lib in (("peer", "0", "0"), ("lib_rccl", "1", "0"), ("rccl", "1", "1")):
     os.environ["CFMM_AMD_NO_PEER"] = no_peer
+    os.environ["CFMM_AMD_NO_LIB_RCCL"] = no_lib
     r = crd.ShardedRouter(obj, market, n, device=lr)
     cr.find_arb_(r, v)
-    rec = {"in_library_collective": isinstance(r._backend, cr.DeviceBackend),
+    rec = {"in_library_collective": isinstance(r._backend, cr.DeviceBackend), "collective": r.collective,
            "fixed_v_netflow_equal": bool(np.array_equal(cr.netflows(r), psi_fixed)),
            "trades_equal": bool(np.array_equal(r.Δs, D_fixed) and np.array_equal(r.Λs, L_fixed))}
     for solver in ("native", "scipy"):

@@ -36,7 +36,8 @@ def test_sharded_paths_world1_rccl_and_peer():
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dist_world1.json"), "w"), indent=1)
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["peer"]["in_library_collective"] and not out["rccl"]["in_library_collective"]
-    for path in ("peer", "rccl"):
+    assert out["lib_rccl"]["in_library_collective"] and "cfmm_rccl_init_rank" in out["lib_rccl"]["collective"]
+    for path in ("peer", "lib_rccl", "rccl"):
         rec = out[path]
         assert rec["fixed_v_netflow_equal"] and rec["trades_equal"]   # world 1: the all-reduce is the identity
         assert rec["route_native_netflow_rel_diff"] <= 1e-9 and rec["route_scipy_netflow_rel_diff"] <= 1e-9
