@@ -42,6 +42,11 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # round the unpinned figure moved by 1.4x (1.35e7 .. 2.39e7 pools/s over rounds 1-4)
 os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("OMP_PROC_BIND", "spread")
+# ... and sleeping between parallel regions: with libgomp's default (spinning) wait 30 % of the 128-thread evaluations on the
+# GPU box took ~90 ms instead of 3 ms (the spinning threads burn the container's CPU quota and the whole cgroup is throttled
+# for the rest of the scheduler period) -- the reason the figure moved between 1.35e7 and 3.4e7 pools/s from round to round
+# (profiles/r05_cpu_baseline_probe.txt: 128 threads, mean 3.4e7 active vs 2.1e8 passive; median 3.1e8 either way)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 import numpy as np
 import torch
@@ -66,10 +71,23 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
     from helpers import oracle_objective, oracle_poolset
 
     ps = oracle_poolset(batches, n)
-    threads = orc.lib().oracle_max_threads()
-    if "TORCHELASTIC_RUN_ID" in os.environ:   # torchrun exports OMP_NUM_THREADS=1; rank 0 is the only rank doing host work here
-        threads = max(1, min(128, max(1, len(os.sched_getaffinity(0)) // 2)))   # one per physical core (SMT siblings only add contention to this memory-bound loop: measured 4e6 pools/s on 256 threads vs 2.3e7 on 128)
     m = ps.m
+    # thread count: the best of {16, 64, one per physical core (<= 128)} on a short calibration -- more threads shorten the sweep
+    # (5.6 -> 1.0 ms from 16 to 128 threads on the GPU box's 2 x EPYC) but not the serial reductions (2 ms), and SMT siblings only
+    # add contention to this memory-bound loop (256 threads: 200 ms per sweep)
+    ncpu = len(os.sched_getaffinity(0))
+    Dc, Lc = np.empty((m, 2)), np.empty((m, 2))
+    best = None
+    for cand in sorted({c for c in (16, 64, min(128, max(1, ncpu // 2))) if c <= ncpu} or {1}):
+        ps.sweep_into(v, Dc, Lc, cand)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            ps.sweep_into(v, Dc, Lc, cand)
+        dt = (time.perf_counter() - t0) / 6
+        if best is None or dt < best[0]:
+            best = (dt, cand)
+    threads = best[1]
+    del Dc, Lc
     # find_arb!(r, v) overwrites r.Δs / r.Λs in place (src/router.jl:40): the outputs are allocated ONCE, like the
     # reference's; the threaded sweep (Threads.@threads, :39) and the two SERIAL reductions of fn / g! (:81-83, :98-100) are
     # timed separately -- at 128 threads the serial part is most of a CPU evaluation (Amdahl), which is what the GPU path's
@@ -105,7 +123,8 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
             "evaluation_ms_quartiles": [float(1e3 * per_rep[int(q * (len(per_rep) - 1))]) for q in (0.25, 0.5, 0.75)],
             "is": "value = pools / (threaded sweep + the reference's two serial reductions); sweep_ms is the Threads.@threads part "
                   "(src/router.jl:39), reductions_ms the single-threaded loops of fn / g! (:81-83, :98-100); value_1thread = the "
-                  "same evaluation on one thread; outputs pre-allocated, OMP_PLACES=cores OMP_PROC_BIND=spread",
+                  "same evaluation on one thread; outputs pre-allocated, OMP_PLACES=cores OMP_PROC_BIND=spread OMP_WAIT_POLICY=passive; "
+                  "thread count = the best of {16, 64, one per physical core} on a short calibration",
             "sample": f"{reps} full evaluations of the same {m}-pool workload (oracle/cfmm_oracle.c: OpenMP sweep + "
                       f"serial dual/gradient reductions), {t_tot:.1f} s of host time; the Julia reference itself "
                       f"cannot run here (no Julia toolchain)"}
@@ -226,7 +245,7 @@ def other_configs(args, local_rank, budget_s):
             # parity at fixed v: the timed path's {Ψ, acc} against ONE sweep of the CPU restatement
             ps = oracle_poolset(sb.batches, sb.n)
             D, L = np.empty((ps.m, 2)), np.empty((ps.m, 2))
-            ps.sweep_into(sb.v, D, L, orc.lib().oracle_max_threads())
+            ps.sweep_into(sb.v, D, L, min(64, len(os.sched_getaffinity(0))))
             G = np.zeros(sb.n)
             orc.grad_scatter(G, D, L, ps.Ai)
             acco = orc.dual_acc(D, L, ps.Ai, sb.v)

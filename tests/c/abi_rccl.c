@@ -62,7 +62,9 @@ static int run_rank(int rank, int world, const unsigned char* id, const double* 
     printf("rank %d/%d: route! %d evaluations, status %d, min psi/scale %.2e\n", rank, world, info.evaluations, info.status, neg);
     CHECK(cfmm_set_rccl_comm(ctx, NULL));                                           /* exchange off: the shard alone again */
     cfmm_ctx_destroy(ctx);
-    return (err <= 1e-12 && neg >= -1e-6 && info.status <= 1) ? 0 : 3;
+    /* status 0 / 1: pgtol / factr; 4: L-BFGS-B's "abnormal termination in line search" at a corner optimum -- the way the Fortran
+     * code itself ends such runs (tests/golden/route_fortran.npz: config 2, config 4's shard); feasibility is the check */
+    return (err <= 1e-12 && neg >= -1e-6 && (info.status <= 1 || info.status == 4)) ? 0 : 3;
 }
 
 int main(int argc, char** argv)
