@@ -10,6 +10,7 @@ if [ -n "$TESTS" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 < /dev/null; tail -4 gpurun_out/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/smoke.log
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "parity_by_convergence" 2>&1 < /dev/null | grep -E "default|passed|failed" > gpurun_out/route_convergence.txt; cat gpurun_out/route_convergence.txt
+  timeout 900 python -m pytest tests/test_route_fortran_pin.py -m gpu -q -s 2>&1 < /dev/null | grep -E "Fortran|passed|failed" > gpurun_out/route_fortran_pin.txt; cat gpurun_out/route_fortran_pin.txt
 fi
 for w in $FULL; do
   steps=100; [ "$w" = "config3" ] && steps=20      # config3 exactly as the driver runs it (--steps 20 --warmup 5)
@@ -38,6 +39,10 @@ for w in $PROF; do
     [ -n "$f" ] && echo "== $w $mode" && head -3 "$f" | cut -c1-200
   done
 done
+if [ -n "$PROF" ]; then   # the row fold launch by launch: span against the idle gap in front of it
+  for w in $PROF; do python $R/scripts/fold_trace.py $R/gpurun_out/prof_${w}_warm; python $R/scripts/fold_trace.py $R/gpurun_out/prof_${w}_cold; done > $R/gpurun_out/fold_trace.txt 2>&1
+  cat $R/gpurun_out/fold_trace.txt
+fi
 for w in $PMC; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${w}_$c -o $w -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-cold --workload $w > $R/gpurun_out/pmc_${w}_$c.log 2>&1 < /dev/null
