@@ -35,6 +35,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HOST_CPUS = len(os.sched_getaffinity(0))   # read NOW: once the OpenMP runtime binds the main thread (OMP_PROC_BIND below) its affinity is one core
 # kernel arguments in device memory: measured 22.2 vs 24.9 us per step (config3) and 7.0 vs 9.1 (config2)
 # against HIP_FORCE_DEV_KERNARG=0; it is the ROCm 7 default on this box, pinned here in case it is not
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
@@ -75,7 +76,7 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
     # thread count: the best of {16, 64, one per physical core (<= 128)} on a short calibration -- more threads shorten the sweep
     # (5.6 -> 1.0 ms from 16 to 128 threads on the GPU box's 2 x EPYC) but not the serial reductions (2 ms), and SMT siblings only
     # add contention to this memory-bound loop (256 threads: 200 ms per sweep)
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu = HOST_CPUS
     Dc, Lc = np.empty((m, 2)), np.empty((m, 2))
     best = None
     for cand in sorted({c for c in (16, 64, min(128, max(1, ncpu // 2))) if c <= ncpu} or {1}):
@@ -116,7 +117,7 @@ def cpu_baseline_leg(name, batches, n, v, psi_dev, route_gpu, budget_s=12.0, rou
         one.append(time.perf_counter() - t0)
     ps.sweep_into(v, D, L, threads)
     per_rep = np.sort(np.array(per_rep))
-    base = {"value": m * reps / t_tot, "unit": "pools/s", "cores": int(threads), "threads": int(threads), "kind": "port",
+    base = {"value": m * reps / t_tot, "unit": "pools/s", "cores": int(threads), "threads": int(threads), "host_cpus": int(ncpu), "kind": "port",
             "sweep_ms": 1e3 * t_sweep / reps, "reductions_ms": 1e3 * t_red / reps,
             "value_sweep_only": m * reps / t_sweep, "value_1thread": m / (min(one) + t_red / reps),
             "sweep_1thread_ms": 1e3 * min(one),
@@ -245,7 +246,7 @@ def other_configs(args, local_rank, budget_s):
             # parity at fixed v: the timed path's {Ψ, acc} against ONE sweep of the CPU restatement
             ps = oracle_poolset(sb.batches, sb.n)
             D, L = np.empty((ps.m, 2)), np.empty((ps.m, 2))
-            ps.sweep_into(sb.v, D, L, min(64, len(os.sched_getaffinity(0))))
+            ps.sweep_into(sb.v, D, L, min(64, HOST_CPUS))
             G = np.zeros(sb.n)
             orc.grad_scatter(G, D, L, ps.Ai)
             acco = orc.dual_acc(D, L, ps.Ai, sb.v)
