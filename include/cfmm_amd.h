@@ -263,8 +263,8 @@ int cfmm_peer_buffer_free(cfmm_ctx* ctx, uint64_t d_buf);
  * -- or hands over a communicator it created itself (cfmm_set_rccl_comm: the caller keeps ownership; NULL switches the
  * exchange off).  RCCL sums in its own (ring / tree) order: every rank receives the SAME bits (the lockstep L-BFGS-B of
  * cfmm_route relies on it), but not the rank-ordered sum of cfmm_set_peers.  cfmm_set_peers (fold + exchange in ONE
- * launch, +1.9 us per step instead of ~+9.5) stays the fast path; this is the portable one and the one the fast path is
- * checked against (cfmmrouter.jl_amd/dist.py).  One exchange at a time per context (CFMM_ERR_STATE otherwise);
+ * launch: no second launch on the critical path of an evaluation) stays the fast path; this is the portable one
+ * (cfmmrouter.jl_amd/dist.py tries the peer exchange first, then this, then torch.distributed).  One exchange at a time per context (CFMM_ERR_STATE otherwise);
  * evaluations are launched when their prices are ready (no pre-arming); n_tokens <= 8192.  RCCL is resolved at first use
  * (the process's own RCCL if it has one loaded globally, else librccl.so.1): CFMM_ERR_UNSUPPORTED if there is none. */
 #define CFMM_RCCL_ID_BYTES 128
