@@ -31,7 +31,7 @@ int fail(const cfmm_ctx* c, int code, const char* fmt, ...)
 
 extern "C" {
 
-const char* cfmm_version(void) { return "cfmm_amd 0.3.0 (gfx950)"; }
+const char* cfmm_version(void) { return "cfmm_amd 0.5.0 (gfx950)"; }
 
 const char* cfmm_last_error(const cfmm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -216,7 +216,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
         {"fast_math", &c->opt_fast_math}, {"armed", &c->opt_armed}, {"arm_timeout_ms", &c->opt_arm_timeout_ms},
         {"cost_geomean", &c->opt_cost_geomean}, {"cost_univ3", &c->opt_cost_univ3}, {"host_flag", &c->opt_host_flag},
         {"stop_in_noise", &c->opt_stop_in_noise}, {"multi_threads", &c->opt_multi_threads},
-        {"debug_stall_ms", &c->opt_debug_stall_ms}, {"debug_dev_trust", &c->opt_debug_dev_trust},
+        {"debug_stall_ms", &c->opt_debug_stall_ms}, {"debug_dev_trust", &c->opt_debug_dev_trust}, {"univ3_heads", &c->opt_univ3_heads},
     };
     for (auto& t : table)
         if (!std::strcmp(key, t.name)) return t.slot;

@@ -380,7 +380,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             return GeoMeanPools{s.R, s.w, s.gamma, s.Ai, s.eta, s.lR, (int)c->opt_geomean_exact, s.pk, gbase_of(s)};
         };
         auto univ3_of = [&](const Segment& s) {
-            return UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ticks, s.thr, s.has_walk, s.cp, s.pk, gbase_of(s)};
+            return UniV3Pools{s.pg, s.Ai, s.cur_a, s.cur_b, s.cur_c, s.curR, s.walk, s.ticks, s.thr,
+                              c->opt_univ3_heads != 0 ? s.head : nullptr, s.has_walk, s.cp, s.pk, gbase_of(s)};
         };
         hipError_t e = hipSuccess;
         if (g.multi) {

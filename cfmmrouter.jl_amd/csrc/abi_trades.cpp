@@ -285,7 +285,8 @@ int cfmm_update_reserves(cfmm_ctx* c)
         Segment& ns = fresh[k];
         (void)hipFree(s.pg); (void)hipFree(s.Ai); (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c);
         (void)hipFree(s.curR); (void)hipFree(s.walk); (void)hipFree(s.ticks); (void)hipFree(s.thr);
-        (void)hipFree(s.cp); (void)hipFree(s.pk);
+        (void)hipFree(s.cp); (void)hipFree(s.pk); (void)hipFree(s.head);
+        s.head = ns.head;
         s.pg = ns.pg; s.Ai = ns.Ai; s.cur_a = ns.cur_a; s.cur_b = ns.cur_b; s.cur_c = ns.cur_c; s.curR = ns.curR;
         s.walk = ns.walk; s.ticks = ns.ticks; s.thr = ns.thr; s.has_walk = ns.has_walk;
         s.cp = ns.cp; s.pk = ns.pk; s.gvals.swap(ns.gvals); s.fast_ok = ns.fast_ok;

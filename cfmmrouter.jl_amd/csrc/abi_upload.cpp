@@ -163,6 +163,7 @@ void free_segment(Segment& s)
     (void)hipFree(s.eta); (void)hipFree(s.lR); (void)hipFree(s.pk);
     (void)hipFree(s.cur_a); (void)hipFree(s.cur_b); (void)hipFree(s.cur_c); (void)hipFree(s.curR);
     (void)hipFree(s.pg); (void)hipFree(s.cp); (void)hipFree(s.walk); (void)hipFree(s.ticks); (void)hipFree(s.thr);
+    (void)hipFree(s.head);
     s = Segment{};
 }
 
@@ -289,7 +290,7 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
         auto work = [&](size_t lo, size_t hi) {
             for (size_t e = lo; e < hi; ++e) {
                 const TickRec& r = ticks[e];
-                if (r.pad != 0.0 || r.dt.x == 0.0 || r.rout == 0.0) continue;
+                if (r.thr != 0.0 || r.dt.x == 0.0 || r.rout == 0.0) continue;   // (thr == 1 marks a closing record until here)
                 thr[e] = drain_threshold(r.ks.x, r.ks.y, r.dt.x);
             }
         };
@@ -298,15 +299,40 @@ int univ3_build(cfmm_ctx* c, Segment& s, int64_t m, const double* current_price,
         work(0, nrec / nthr);
         for (auto& th : pool) th.join();
     }
+    for (size_t e = 0; e < ticks.size(); ++e) ticks[e].thr = thr[e];   // every record carries its own threshold (closing records: 0)
     thr.resize(ticks.size() + 4, 0.0);   // the scan reads four thresholds at a time
     s.has_walk = longest > 0 ? 1 : 0;
+    // threshold heads (sweep.h UniV3Pools::head): the first four thresholds of both lists of every pool as floats rounded DOWN
+    std::vector<uint4> head;
+    if (s.has_walk) {
+        head.resize(2 * (size_t)m);
+        const auto enc = [](double T) -> unsigned {
+            if (T == 0.0) return 0u;                                   // never drains (also: closing record, past the list)
+            if (!(T >= 0x1p-120 && T <= 0x1p120)) return 0x7fc00000u;   // outside the comfortable binary32 range: NaN = "ask thr[]"
+            float f = (float)T;
+            if ((double)f > T) f = std::nextafterf(f, 0.0f);           // round toward zero = down (T > 0)
+            unsigned b;
+            std::memcpy(&b, &f, sizeof b);
+            return b;
+        };
+        for (int64_t i = 0; i < m; ++i) {
+            const int4 w = walk[(size_t)i];
+            unsigned h[8];
+            for (int k = 0; k < 4; ++k) {
+                h[k] = k < w.y ? enc(thr[(size_t)w.x + k]) : 0u;       // beyond the list: the closing record's "never"
+                h[4 + k] = k < w.w ? enc(thr[(size_t)w.z + k]) : 0u;
+            }
+            head[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]);
+            head[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+    }
     s.fast_ok = fast ? 1 : 0;
     int rc;
     if ((rc = upload(c, &s.pg, pg.data(), (size_t)m)) || (rc = upload(c, &s.Ai, Ai, (size_t)m)) ||
         (rc = upload(c, &s.cur_a, cur_a.data(), (size_t)m)) || (rc = upload(c, &s.cur_b, cur_b.data(), (size_t)m)) ||
         (rc = upload(c, &s.cur_c, cur_c.data(), (size_t)m)) || (rc = upload(c, &s.curR, curR.data(), (size_t)m)) ||
         (rc = upload(c, &s.walk, walk.data(), (size_t)m)) || (rc = upload(c, &s.ticks, ticks.data(), ticks.size())) ||
-        (rc = upload(c, &s.thr, thr.data(), thr.size())) ||
+        (rc = upload(c, &s.thr, thr.data(), thr.size())) || (rc = upload(c, &s.head, head.data(), head.size())) ||
         (rc = upload(c, &s.cp, current_price, (size_t)m)) || (rc = build_packed(c, s, m, gamma, Ai))) {
         free_segment(s);
         return rc;

@@ -53,6 +53,7 @@ struct Segment {
     int4* walk = nullptr;
     TickRec* ticks = nullptr;   // univ3: walk lists (sweep.h TickRec)
     double* thr = nullptr;      // univ3: drain thresholds, one per record
+    uint4* head = nullptr;      // univ3: per pool the first four thresholds of both walk lists as rounded-down floats (sweep.h UniV3Pools)
     // launch geometry (decided by ensure_geometry)
     int block = kMidBlock;
     int grid = 0;
@@ -197,6 +198,7 @@ struct cfmm_ctx {
     int64_t opt_stop_in_noise = 0; // cfmm_route: 1 = end the run when a line-search trial point sits on the rounding-noise floor
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
+    int64_t opt_univ3_heads = 1;   // 1: multi-tick UniV3 walks decide their first four list ticks from the per-pool float threshold heads
     int64_t opt_debug_dev_trust = 0; // A/B hook: 1 = device-pointer sweeps launch the fast kernels on trust (round 4's behaviour: a price
                                      //    outside the window poisons the output) instead of the kernels that carry both arithmetics
     int64_t opt_debug_stall_ms = 0; // test hook: the next armed evaluation is preceded by a host stall of this length (once)

@@ -61,7 +61,8 @@ struct alignas(64) TickRec {
     double2 ks;                  // {k, R_in + alpha_in}
     double2 dt;                  // {delta_max, R_out + beta_out}
     double rout;                 // R_out
-    double pad;
+    double thr;                  // this tick's drain threshold (the same value as UniV3Pools::thr[...]; 0: never / closing record): the
+                                 // walk's 2^-40 band test needs it exactly where the record is already in registers
     double2 psum;                // {Σδ, Σλ} of the current tick and of every list tick BEFORE this one, all drained, summed in
                                  // walk order (UniV3Ops::solve_dir); every list is closed by a record that carries only this
 };
@@ -76,6 +77,13 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     const TickRec* ticks;        // [W] the walk lists: per pool the non-empty ticks above, then below, its current one, each
                                  //     list closed by one extra record (psum of the whole list)
     const double* thr;           // [W] per record: the largest price at which the walk drains that tick (0: never / closing record)
+    const uint4* head;           // [2m] or null.  Round 5: the first FOUR drain thresholds of pool i's two walk lists ({up, down} =
+                                 //     head[2i], head[2i+1]) as binary32 values rounded DOWN (bits; 0 = never drains, a NaN pattern =
+                                 //     "not representable: ask the exact array"), read with the pool's other coalesced streams.  With
+                                 //     lo = the float and hi = the next float up, lo <= T <= hi: price <= lo proves that the tick
+                                 //     drains, price > hi proves that it does not, anything in between falls back to the exact scan
+                                 //     of thr[] -- so the walk decisions are the exact ones, while four of five walking pools no longer
+                                 //     touch thr[] (whose 128-byte lines were being fetched almost in full for 32 useful bytes each)
     int has_walk;                // 0: no pool of the segment has a tick beyond its current one (every BoundedProduct
                                  //    pool): the walk spans are not even loaded
     const double* cp;            // [m] current_price alone, read with pk instead of pg + Ai (packed records)

@@ -463,7 +463,11 @@ struct GeoMeanLogOps {
 // in, whatever the number of ticks in between, empty ticks cost nothing, and a pool that trades inside its
 // current tick (the common case; every BoundedProduct pool) touches only coalesced per-pool
 // streams.  `initial` (:352,:374) can only be true on the current tick, and only if it is non-empty.
-struct UniV3Ops {
+// HEADS: the walk consults the per-pool threshold heads (UniV3Pools::head) -- segments with walk lists.  The lean
+// instantiation (BoundedProduct segments: no list anywhere, config 5) carries neither the loads nor the registers
+// (same-box A/B: 21.2 vs 21.5 us HBM-resident on config5 with the head code compiled in).
+template <bool HEADS>
+struct UniV3OpsT {
     static constexpr bool kNeedsLogPrices = false;
     static constexpr bool kPrefetch = false;     // (measured +4 % on the multi-tick walk, +-0 on BoundedProduct segments)
     struct Raw {
@@ -471,6 +475,7 @@ struct UniV3Ops {
         double cc;
         int2 ai;              // packed: {tok, gidx} until resolve()
         int4 walk;
+        uint4 hu, hd;         // threshold heads of the two walk lists (UniV3Pools::head; zeros without one)
         int64_t i;
         double yg;
     };
@@ -483,6 +488,13 @@ struct UniV3Ops {
         r.cb = p.cur_b[i];
         r.cc = p.cur_c[i];
         r.walk = p.has_walk ? p.walk[i] : make_int4(0, 0, 0, 0);
+        r.hu = r.hd = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (HEADS) {
+            if (p.head) {                                 // (kernel argument: uniform) 32 contiguous bytes per lane
+                r.hu = p.head[2 * i];
+                r.hd = p.head[2 * i + 1];
+            }
+        }
         r.i = i;
         r.yg = 0.0;
         if constexpr (GBINS) {
@@ -612,22 +624,56 @@ struct UniV3Ops {
         int j = 0;
         const bool jump = cur != kCurPartial && count > 0;
         TickRec rec;
-        double thr_j = 0.0;                                                // T[j] of the tick the scan stopped at
+        double thr_j = 0.0;                                                // T[j] of the tick the scan stopped at (TickRec::thr)
         bool have = false;
         if (jump) {
-            // ticks 0..j−1 drain.  Four thresholds per round trip (the dependent chain of a walking pool is
-            // walk span -> thresholds -> one record); every list ends in a 0 and the array is padded, so reading past
-            // a short list is harmless and the first failing test ends the scan exactly like one-by-one.
-            const double* T = p.thr + begin;
-            for (;;) {
-                const double t0 = T[j], t1 = T[j + 1], t2 = T[j + 2], t3 = T[j + 3];
-                const int adv = !(price <= t0) ? 0 : !(price <= t1) ? 1 : !(price <= t2) ? 2 : !(price <= t3) ? 3 : 4;
-                thr_j = adv == 0 ? t0 : adv == 1 ? t1 : adv == 2 ? t2 : t3;
-                j += adv;
-                if (adv < 4 || j >= count) break;
+            // ticks 0..j−1 drain.  Round 5: the first four list ticks are decided from the pool's threshold head -- binary32
+            // values rounded DOWN at upload, so with lo = the float and hi = the next float up (lo <= T <= hi):
+            // price <= lo PROVES the tick drains, price > hi PROVES it does not; a price in between (a relative 2^-23 band
+            // around a threshold), a threshold outside the float range (NaN pattern) or a walk deeper than four ticks falls
+            // back to the exact array below.  Same decisions as the exact scan, without touching thr[] for ~4 of 5 walkers.
+            bool exact = true;                                             // the exact scan (still) has to run, from tick j
+            // T[j] of the tick the scan stops at, for the band test below -- from the scan's own registers, NOT from the record
+            // (measured: taking it from rec.thr makes the walk wait for the record earlier, 44.4 -> 49.2 us with the heads off).
+            // The head path knows only hi >= T[j]: good enough, the test "price > T[j](1 + 2^-40)" is then merely conservative
+            // (a price inside (T[j], hi](1 + 2^-40) visits one more tick, which returns zeros and ends the walk the same way).
+            double thr_t = 0.0;
+            if (HEADS && p.head) {
+                const uint4 h = up ? r.hu : r.hd;
+                const unsigned hb[4] = {h.x, h.y, h.z, h.w};
+                int adv = 0;
+                bool stop = false, amb = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double lo = (double)__uint_as_float(hb[k]), hi = (double)__uint_as_float(hb[k] + 1u);
+                    const bool go = !stop && !amb;
+                    const bool drains = price <= lo, not_drains = hb[k] == 0u || price > hi;   // (0 = never; NaN: neither)
+                    adv += (go && drains) ? 1 : 0;
+                    thr_t = (go && !drains && not_drains) ? (hb[k] == 0u ? 0.0 : hi) : thr_t;
+                    stop = stop || (go && !drains && not_drains);
+                    amb = amb || (go && !drains && !not_drains);
+                }
+                if (!amb) {
+                    j = adv;
+                    exact = !stop && j < count;        // all four drain and the list goes on: the exact scan continues at tick 4
+                }
+            }
+            if (exact) {
+                // Four thresholds per round trip (the dependent chain of a walking pool is
+                // walk span -> thresholds -> one record); every list ends in a 0 and the array is padded, so reading past
+                // a short list is harmless and the first failing test ends the scan exactly like one-by-one.
+                const double* T = p.thr + begin;
+                for (;;) {
+                    const double t0 = T[j], t1 = T[j + 1], t2 = T[j + 2], t3 = T[j + 3];
+                    const int adv = !(price <= t0) ? 0 : !(price <= t1) ? 1 : !(price <= t2) ? 2 : !(price <= t3) ? 3 : 4;
+                    thr_t = adv == 0 ? t0 : adv == 1 ? t1 : adv == 2 ? t2 : t3;
+                    j += adv;
+                    if (adv < 4 || j >= count) break;
+                }
             }
             j = j < count ? j : count;   // (prices <= 0 from a caller's device vector pass every test, the closing 0 included)
             rec = p.ticks[begin + j];                                      // (j == count: the list's closing record)
+            thr_j = thr_t;                                                 // T[j] (or the float just above it) of the tick the scan stopped at
             have = true;
             sd = rec.psum.x;
             sl = rec.psum.y;
@@ -640,7 +686,7 @@ struct UniV3Ops {
             double dj, lj;
             if (!have) {
                 rec = p.ticks[begin + j];
-                if (jump) thr_j = p.thr[begin + j];
+                thr_j = rec.thr;
             }
             have = false;
             list_tick<FAST>(rec, price, yp, dj, lj);
@@ -654,6 +700,9 @@ struct UniV3Ops {
         return up ? kDir1 : kDir2;
     }
 };
+
+using UniV3Ops = UniV3OpsT<true>;
+using UniV3OpsLean = UniV3OpsT<false>;
 
 // ---------------------------------------------------------------------------------------------
 // The sweep: src/router.jl:38-42 fused with :79-83 and :98-100
@@ -1337,7 +1386,7 @@ size_t sweep_lds_bytes(int n_pad, int copies, int block, int need_logv, int gtab
     return words * sizeof(double);
 }
 
-// Kernel instantiations (round 5: 68).  Per family {full-range, fast, auto} x {materialising, fused} x {512, 1024 threads};
+// Kernel instantiations (round 5: 82).  Per family {full-range, fast, auto} x {materialising, fused} x {512, 1024 threads};
 // the reference-order GeometricMean forms and the large-market mode (GBINS, 512 threads) run full-range only.
 template <class Ops, int FASTK>
 static hipError_t set_lds_attr(size_t bytes)
@@ -1403,7 +1452,10 @@ hipError_t prepare_kernels(size_t max_lds_bytes)
     if ((e = set_lds_attr<GeoMeanLogOps, kArithAuto>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = set_lds_attr<UniV3Ops, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = set_lds_attr<UniV3Ops, kArithFast>(max_lds_bytes)) != hipSuccess) return e;
-    return set_lds_attr<UniV3Ops, kArithAuto>(max_lds_bytes);
+    if ((e = set_lds_attr<UniV3Ops, kArithAuto>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<UniV3OpsLean, kArithFull>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds_attr<UniV3OpsLean, kArithFast>(max_lds_bytes)) != hipSuccess) return e;
+    return set_lds_attr<UniV3OpsLean, kArithAuto>(max_lds_bytes);
 }
 
 template <class Ops, int FASTK>
@@ -1450,7 +1502,8 @@ hipError_t launch_sweep(const GeoMeanPools& p, const SweepArgs& a, const LaunchC
 }
 hipError_t launch_sweep(const UniV3Pools& p, const SweepArgs& a, const LaunchCfg& c, bool mat, hipStream_t s)
 {
-    return launch_any(UniV3Ops{p}, a, c, mat, s);
+    if (p.head && !a.gflow) return launch_any(UniV3Ops{p}, a, c, mat, s);
+    return launch_any(UniV3OpsLean{p}, a, c, mat, s);
 }
 
 hipError_t launch_reduce(const double* partials, int rows, int n1, int pitch, double* out, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
