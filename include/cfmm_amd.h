@@ -90,7 +90,11 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     Ai when a launch's distinct fees fit a 256-entry table), "compact_trades" (default 1: a
  *                     materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2,
  *                     Lambda1}, a two-coin trade has one direction -- plus overflow rows for pools whose four values
- *                     do not fit that form; cfmm_get_trades* / cfmm_trades_dev return the reference's rows bit for bit)
+ *                     do not fit that form; cfmm_get_trades* / cfmm_trades_dev return the reference's rows bit for bit),
+ *                     "univ3_heads" (default 1: multi-tick UniV3 walks decide their first four list ticks from a per-pool
+ *                     head of rounded-down binary32 thresholds read with the pool's coalesced streams, and consult the
+ *                     exact threshold array only for deeper walks or a price within 2^-23 of a threshold: same decisions,
+ *                     same bits, 11 % fewer bytes; 0: always the exact array)
  *   arithmetic        "fast_math" (default 1: where every operand lies in [2^-150, 2^150] -- pool constants checked at
  *                     upload, prices by the host (host-pointer calls, cfmm_route) and again by every block as it stages
  *                     them; the library then launches kernels in which divisions and square roots run the compiler's
