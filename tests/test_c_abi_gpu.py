@@ -64,6 +64,24 @@ def test_rccl_all_reduce_from_a_plain_c_host(tmp_path):
     assert "rank 0/1" in r.stdout and "route!" in r.stdout
 
 
+@pytest.mark.gpu
+def test_rccl_all_reduce_across_physical_gpus_if_there_are_several(tmp_path):
+    """The same plain-C client with one rank per GPU (forked processes, the 128-byte id handed over by inheritance): every
+    rank holds 1 / N of the market and must return the psi of the WHOLE market -- north_star's collective over xGMI.  Needs
+    N >= 2 GPUs: skipped on the 1-GPU box, runs wherever the suite meets a multi-GPU node."""
+    import torch
+    n_gpus = torch.cuda.device_count()
+    if n_gpus < 2:
+        pytest.skip("one GPU visible: the multi-rank RCCL run needs at least two")
+    world = min(n_gpus, 8)
+    exe = _build_c("abi_rccl", tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=600, env=env)
+    print(r.stdout, r.stderr[-2000:])
+    assert r.returncode == 0 and "RCCL_ABI_OK" in r.stdout
+    assert r.stdout.count("rel err vs unsharded") == world
+
+
 def test_rccl_client_compiles():
     """CPU: the RCCL client is valid C against the header and links against the library (no RCCL needed to link: it is
     resolved at first use)."""
