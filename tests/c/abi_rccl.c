@@ -1,9 +1,10 @@
 /* Plain-C client of the RCCL entry points of libcfmm_amd.so (include/cfmm_amd.h): north_star's "RCCL all-reduce of psi and
  * grad g over xGMI per outer iteration" reached from a non-Python host in three calls.  usage: abi_rccl [world]
  *   world = 1 (default): one process, one rank -- the communicator path end to end on one GPU (run by tests/test_c_abi_gpu.py);
- *   world = N > 1:       forks N - 1 more processes, rank r on GPU r, the 128-byte id handed over through a pipe -- what a
- *                        launcher (MPI, a Julia Distributed worker pool) does with it; every rank holds 1/N of the market and
- *                        must return the psi of the WHOLE market (needs N GPUs: the driver's node, not the 1-GPU box).
+ *   world = N > 1:       forks N processes BEFORE any HIP call, rank r on GPU r; rank 0 draws the 128-byte id and writes it into
+ *                        one pipe per peer -- what a launcher (MPI_Bcast, a Julia Distributed remotecall) does with it; every
+ *                        rank holds 1/N of the market and must return the psi of the WHOLE market (needs N GPUs: the driver's
+ *                        node, not the 1-GPU box; tests/test_c_abi_gpu.py runs it wherever it sees several GPUs).
  * Market: 40 000 ProductTwoCoin pools over 16 tokens from a fixed LCG; checked against the unsharded sweep of the same pools. */
 #include <math.h>
 #include <stdio.h>
@@ -67,6 +68,21 @@ static int run_rank(int rank, int world, const unsigned char* id, const double* 
     return (err <= 1e-12 && neg >= -1e-6 && (info.status <= 1 || info.status == 4)) ? 0 : 3;
 }
 
+/* the whole market on one context, no exchange: what every rank of the sharded run must reproduce */
+static int reference(int device, double* psi_ref, double* acc_ref)
+{
+    cfmm_ctx* ctx = NULL;
+    int rank = device;
+    if (cfmm_ctx_create(device, N, &ctx) != CFMM_OK) {
+        fprintf(stderr, "cfmm_ctx_create: %s\n", cfmm_last_error(NULL));
+        return 2;
+    }
+    CHECK(cfmm_pools_add_product(ctx, M, R, g, Ai));
+    CHECK(cfmm_eval(ctx, v, psi_ref, acc_ref));
+    cfmm_ctx_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const int world = argc > 1 ? atoi(argv[1]) : 1;
@@ -79,34 +95,46 @@ int main(int argc, char** argv)
         Ai[2 * i + 1] = b;
     }
     for (int j = 0; j < N; ++j) v[j] = exp(0.3 * sin(1.7 * j));
-    /* the reference: the whole market on one context, no exchange */
-    double psi_ref[N], acc_ref;
-    {
-        cfmm_ctx* ctx = NULL;
-        int rank = -1;
-        if (cfmm_ctx_create(0, N, &ctx) != CFMM_OK) {
-            fprintf(stderr, "cfmm_ctx_create: %s\n", cfmm_last_error(NULL));
-            return 2;
-        }
-        CHECK(cfmm_pools_add_product(ctx, M, R, g, Ai));
-        CHECK(cfmm_eval(ctx, v, psi_ref, &acc_ref));
-        cfmm_ctx_destroy(ctx);
-    }
-    unsigned char id[CFMM_RCCL_ID_BYTES];
-    {
+    if (world <= 1) {
+        double psi_ref[N], acc_ref;
+        unsigned char id[CFMM_RCCL_ID_BYTES];
         cfmm_ctx* ctx = NULL;
         int rank = 0;
+        if (reference(0, psi_ref, &acc_ref) != 0) return 2;
         CHECK(cfmm_rccl_unique_id(id));                                             /* call 1 of 3: rank 0 */
+        return run_rank(0, 1, id, psi_ref, acc_ref);
     }
-    if (world <= 1) return run_rank(0, 1, id, psi_ref, acc_ref);
-    /* call "broadcast": here a fork -- the children inherit the id (a real launcher sends the 128 bytes) */
+    /* N ranks: fork FIRST (a HIP runtime does not survive fork), one pipe per rank > 0 for the 128-byte id -- the
+     * "broadcast" a real launcher does with MPI_Bcast / a Distributed.jl remotecall */
+    int pipes[64][2];
     pid_t kids[64];
-    for (int r = 1; r < world && r < 64; ++r) {
+    if (world > 64) return 2;
+    for (int r = 1; r < world; ++r)
+        if (pipe(pipes[r]) != 0) return 2;
+    for (int r = 0; r < world; ++r) {
         kids[r] = fork();
-        if (kids[r] == 0) _exit(run_rank(r, world, id, psi_ref, acc_ref));
+        if (kids[r] == 0) {
+            double psi_ref[N], acc_ref;
+            unsigned char id[CFMM_RCCL_ID_BYTES];
+            cfmm_ctx* ctx = NULL;
+            int rank = r;
+            if (reference(r, psi_ref, &acc_ref) != 0) _exit(2);                     /* the whole market on this rank's GPU */
+            if (r == 0) {
+                if (cfmm_rccl_unique_id(id) != CFMM_OK) {                           /* call 1 of 3: rank 0 */
+                    fprintf(stderr, "rank 0: cfmm_rccl_unique_id: %s\n", cfmm_last_error(ctx));
+                    _exit(1);
+                }
+                for (int q = 1; q < world; ++q)
+                    if (write(pipes[q][1], id, sizeof id) != (ssize_t)sizeof id) _exit(1);
+            } else if (read(pipes[r][0], id, sizeof id) != (ssize_t)sizeof id) {
+                _exit(1);
+            }
+            (void)rank;
+            _exit(run_rank(r, world, id, psi_ref, acc_ref));
+        }
     }
-    int rc = run_rank(0, world, id, psi_ref, acc_ref);
-    for (int r = 1; r < world && r < 64; ++r) {
+    int rc = 0;
+    for (int r = 0; r < world; ++r) {
         int st = 0;
         waitpid(kids[r], &st, 0);
         if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 4;

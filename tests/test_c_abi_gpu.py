@@ -66,7 +66,7 @@ def test_rccl_all_reduce_from_a_plain_c_host(tmp_path):
 
 @pytest.mark.gpu
 def test_rccl_all_reduce_across_physical_gpus_if_there_are_several(tmp_path):
-    """The same plain-C client with one rank per GPU (forked processes, the 128-byte id handed over by inheritance): every
+    """The same plain-C client with one rank per GPU (processes forked before any HIP call, the 128-byte id handed over through pipes): every
     rank holds 1 / N of the market and must return the psi of the WHOLE market -- north_star's collective over xGMI.  Needs
     N >= 2 GPUs: skipped on the 1-GPU box, runs wherever the suite meets a multi-GPU node."""
     import torch
