@@ -10,7 +10,8 @@ from cfmmrouter_amd._lib import OBJ_LINEAR_NONNEGATIVE
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 n = 96
-batches = [synth.product_pools(40_000, n, seed=1), synth.geomean_pools(20_000, n, seed=2), synth.bounded_product_pools(15_000, n, seed=3)]
+batches = [synth.product_pools(40_000, n, seed=1), synth.geomean_pools(20_000, n, seed=2), synth.bounded_product_pools(15_000, n, seed=3),
+           synth.univ3_ragged_pools(12_000, n, seed=4)]       # (round 5: multi-tick ladders too -- the threshold heads)
 a, b = cr.DeviceBackend(n, batches), cr.DeviceBackend(n, batches)
 b.ctx.set_option("armed", 0); b.ctx.set_option("host_flag", 0)
 for be in (a, b):
