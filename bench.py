@@ -276,6 +276,53 @@ def other_configs(args, local_rank, budget_s):
     return out
 
 
+def at_scale_leg(args, local_rank, m=8_000_000, n=256):
+    """The same ProductTwoCoin sweep where the launch floor no longer matters: 8M pools (320 MB touched per sweep: HBM-resident
+    by size, rotated over 3 copies all the same), kernel span by CP events -- the roofline figure of the KERNEL rather than of
+    the 1M-pool configuration (scripts/size_scaling.py prints the whole curve: profiles/r05_size_scaling.txt)."""
+    from benchlib.workloads import HBM_PEAK_GBS, ring_copies, touched_bytes
+    t0 = time.perf_counter()
+    batch = [synth_mod().product_pools(m, n, seed=1234)]
+    copies = ring_copies(touched_bytes(batch, True))
+    ring = [cr.DeviceBackend(n, batch, device=local_rank) for _ in range(copies)]
+    try:
+        stream = torch.cuda.current_stream()
+        v_t = torch.from_numpy(synth_mod().sweep_prices(n, seed=1234)).to("cuda")
+        out_t = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        for b_ in ring:
+            b_.ctx.set_stream(stream.cuda_stream)
+        K = 8 * copies
+        for k in range(2 * copies):
+            ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(K):
+            ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), True)
+        torch.cuda.synchronize()
+        step_ms = 1e3 * (time.perf_counter() - t1) / K
+        for b_ in ring:
+            b_.ctx.set_option("time_kernels", 1)
+            b_.ctx.kernel_times()
+        for k in range(K):
+            ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), True)
+        torch.cuda.synchronize()
+        sw = sum(b_.ctx.kernel_times()["sweep_ms"] for b_ in ring) / K
+    finally:
+        for b_ in ring:
+            b_.close()
+    return {"workload": f"{m} ProductTwoCoin pools, {n} tokens, materialising, HBM-resident ({copies} copies x {touched_bytes(batch, True) / 1e6:.0f} MB touched)",
+            "pools": m, "kernel_ms": sw, "ms_per_step": step_ms, "value": m / (step_ms * 1e-3),
+            "frac": 64.0 * m / (sw * 1e-3) / 1e9 / HBM_PEAK_GBS, "bus_frac": 40.0 * m / (sw * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "is": "frac = reference-layout bytes (64 B per pool, SURVEY 8d) / kernel time / 8 TB/s; bus_frac = the 40 B per pool this "
+                  "layout moves (24 read + 16 written) / kernel time / 8 TB/s (a streaming copy reaches ~0.79 of 8 TB/s)",
+            "seconds": time.perf_counter() - t0}
+
+
+def synth_mod():
+    from cfmmrouter_amd import synth
+    return synth
+
+
 def summary_string(rec):
     """<= 120 characters: what a parser that keeps only scalars of `config` still shows of a workload"""
     if "error" in rec:
@@ -538,6 +585,13 @@ def main():
         for k, rec in line["configs"].items():
             if isinstance(rec, dict):
                 line["config"]["cfg_" + k] = summary_string(rec)
+        try:     # the kernel against the roofline where the launch floor no longer matters
+            sc = at_scale_leg(args, local_rank)
+            line["roofline"]["at_scale"] = sc
+            line["config"]["at_scale"] = "8M Product pools HBM-resident: kernel %.1fus = frac %.2f (ref. bytes) bus %.2f of 8 TB/s; %.2e pools/s" % (
+                1e3 * sc["kernel_ms"], sc["frac"], sc["bus_frac"], sc["value"])
+        except Exception as e:
+            line["roofline"]["at_scale"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(line))
     if use_dist:
