@@ -23,6 +23,9 @@ for m in sizes:
     ring = [cr.DeviceBackend(n, batch) for _ in range(copies)]
     for b in ring:
         b.ctx.set_stream(stream.cuda_stream)
+        for kv in filter(None, os.environ.get("OPTS", "").split(",")):      # OPTS="max_grid=512,block=1024": library options
+            k_, val = kv.split("=")
+            b.ctx.set_option(k_, int(val))
     K = max(3 * copies, 24)
     for k in range(2 * copies):
         ring[k % copies].ctx.sweep_dev(v_t.data_ptr(), out_t.data_ptr(), True)
