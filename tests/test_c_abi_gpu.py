@@ -65,6 +65,8 @@ def test_rccl_all_reduce_from_a_plain_c_host(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="first contact with a multi-GPU node: this path has never crossed a physical xGMI link; a "
+                                        "failure is reported (XFAIL), a pass too (XPASS), neither stops the suite")
 def test_rccl_all_reduce_across_physical_gpus_if_there_are_several(tmp_path):
     """The same plain-C client with one rank per GPU (processes forked before any HIP call, the 128-byte id handed over through pipes): every
     rank holds 1 / N of the market and must return the psi of the WHOLE market -- north_star's collective over xGMI.  Needs
