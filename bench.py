@@ -41,8 +41,23 @@ HOST_CPUS = len(os.sched_getaffinity(0))   # read NOW: once the OpenMP runtime b
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # the CPU restatement's OpenMP threads (cpu_baseline leg only): one per core, spread over the sockets, pinned -- round to
 # round the unpinned figure moved by 1.4x (1.35e7 .. 2.39e7 pools/s over rounds 1-4)
-os.environ.setdefault("OMP_PLACES", "cores")
-os.environ.setdefault("OMP_PROC_BIND", "spread")
+def _single_process_run():
+    """True when this process is the only rank on the box (no torchrun world, no --gpus N > 1 about to re-exec under it)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return False
+    for k, a in enumerate(sys.argv):
+        if a == "--gpus" and k + 1 < len(sys.argv) and sys.argv[k + 1] != "1":
+            return False
+        if a.startswith("--gpus=") and a != "--gpus=1":
+            return False
+    return True
+
+
+if _single_process_run():
+    # (NOT at N > 1: the OpenMP runtime binds every process's MAIN thread to the first place when it starts, so eight ranks would
+    #  drive their GPUs from one core; and the environment would be inherited by the ranks this script re-executes itself as)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
 # ... and sleeping between parallel regions: with libgomp's default (spinning) wait 30 % of the 128-thread evaluations on the
 # GPU box took ~90 ms instead of 3 ms (the spinning threads burn the container's CPU quota and the whole cgroup is throttled
 # for the rest of the scheduler period) -- the reason the figure moved between 1.35e7 and 3.4e7 pools/s from round to round
