@@ -7,11 +7,21 @@
 // hand-rolling: a Julia / C host needs three calls (cfmm_rccl_unique_id on rank 0, its own broadcast of 128 bytes,
 // cfmm_rccl_init_rank everywhere).
 //
-// RCCL is resolved at FIRST USE, not at load time (librccl.so is a 570 MB object; single-GPU users never touch it):
-// ncclAllReduce & co. are looked up in the process's global scope first -- a host that created `comm` itself has the RCCL
-// that owns it there -- and in librccl.so.1 (ROCm's soname) otherwise.
+// RCCL is resolved at FIRST USE, not at load time (librccl.so is a 570 MB object; single-GPU users never touch it), and
+// ALL entry points come from ONE library image -- a communicator must only ever meet the ncclAllReduce of the RCCL that
+// created it:
+//   1. CFMM_AMD_RCCL_LIB (environment: a path or soname) names the image -- the host that hands over its own communicator
+//      (cfmm_set_rccl_comm) says which RCCL owns it; nothing else is tried, a failure is CFMM_ERR_UNSUPPORTED;
+//   2. else the process's GLOBAL scope, if ncclAllReduce is visible there (a host linked against RCCL): all five symbols
+//      must then resolve there;
+//   3. else dlopen("librccl.so.1") (ROCm's soname: an image already loaded under that soname -- e.g. a framework's bundled
+//      copy -- is the one returned), then /opt/rocm/lib/librccl.so.1.
+// cfmm_set_rccl_comm accepts a foreign communicator only under 1. or 2. (under 3. the library cannot know that the caller's
+// communicator belongs to the image it found by itself); cfmm_rccl_init_rank creates its communicator with the resolved
+// image and works under all three.
 #include "ctx.h"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -25,7 +35,9 @@ struct Rccl {
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*error_string)(ncclResult_t) = nullptr;
-    std::string why;   // non-empty: resolution failed
+    std::string why;      // non-empty: resolution failed
+    std::string source;   // "CFMM_AMD_RCCL_LIB=...", "global scope" or the soname / path the library opened by itself
+    bool caller_named = false;   // resolved under rule 1 or 2: the caller's own RCCL
     bool ok = false;
 };
 
@@ -34,15 +46,37 @@ Rccl& rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = nullptr;
-        auto sym = [&](const char* name) -> void* {
-            void* p = dlsym(RTLD_DEFAULT, name);
-            if (!p) {
-                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-                if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-                if (h) p = dlsym(h, name);
+        void* h = nullptr;             // RTLD_DEFAULT is a null handle on glibc: `global` tells the two apart
+        bool global = false;
+        std::string tried;
+        auto open = [&](const char* name) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) {
+                r.source = name;
+                return true;
             }
-            if (!p && r.why.empty()) r.why = std::string("RCCL symbol ") + name + " not found (librccl.so.1: " + (h ? "loaded" : (dlerror() ? dlerror() : "not loadable")) + ")";
+            const char* de = dlerror();        // ONE call: dlerror() clears the message it returns
+            tried += std::string(tried.empty() ? "" : "; ") + name + ": " + (de ? de : "not loadable");
+            return false;
+        };
+        const char* named = std::getenv("CFMM_AMD_RCCL_LIB");
+        if (named && *named) {
+            r.caller_named = true;
+            if (open(named)) r.source = std::string("CFMM_AMD_RCCL_LIB=") + named;
+        } else if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
+            global = true;
+            r.caller_named = true;
+            r.source = "global scope";
+        } else if (!open("librccl.so.1")) {
+            open("/opt/rocm/lib/librccl.so.1");
+        }
+        if (!h && !global) {
+            r.why = "RCCL is not available (" + tried + ")";
+            return;
+        }
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(global ? RTLD_DEFAULT : h, name);
+            if (!p && r.why.empty()) r.why = std::string("RCCL symbol ") + name + " not found in " + r.source;
             return p;
         };
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(sym("ncclGetUniqueId"));
@@ -106,6 +140,10 @@ int cfmm_set_rccl_comm(cfmm_ctx* c, void* comm)
     if (comm && !c->peers.empty())
         return fail(c, CFMM_ERR_STATE, "cfmm_set_peers is active on this context: one exchange at a time (cfmm_set_peers(ctx, NULL, 0, 0, 0) first)");
     if (comm && !rccl().ok) return fail(c, CFMM_ERR_UNSUPPORTED, "%s", rccl().why.c_str());
+    if (comm && !rccl().caller_named)
+        return fail(c, CFMM_ERR_UNSUPPORTED,
+                    "cannot tell which RCCL owns this communicator: ncclAllReduce is not in the process's global scope and the library "
+                    "resolved %s by itself -- name the owning image in CFMM_AMD_RCCL_LIB (or use cfmm_rccl_init_rank)", rccl().source.c_str());
     rccl_release(c);
     c->rccl_comm = comm;      // caller-owned (NULL: back to single-GPU operation)
     c->rccl_owned = false;

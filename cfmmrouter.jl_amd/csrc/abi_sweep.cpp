@@ -470,16 +470,20 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         if (bracket) HIP_TRY(c, hipEventRecord(rb, c->stream));
         c->pending.push_back({ra, rb, 1});
     }
-    if (rccl) {   // north_star: "RCCL all-reduce of Ψ and ∇g over xGMI per outer iteration" -- n + 1 doubles, on the same stream
-        rc = rccl_all_reduce_out(c, d_out);
-        if (rc != CFMM_OK) return rc;
-    }
+    // the sweep and its fold ARE on the stream from here on: the context's bookkeeping says so whatever the collective does
     if (materialize) {
         c->have_trades = true;
         c->x_valid = false;
         c->trades_compact = (c->opt_compact_trades != 0 && !gb) ? 1 : 0;
     }
     ++c->sweep_count;
+    if (rccl) {   // north_star: "RCCL all-reduce of Ψ and ∇g over xGMI per outer iteration" -- n + 1 doubles, on the same stream
+        rc = rccl_all_reduce_out(c, d_out);
+        if (rc != CFMM_OK) {
+            c->have_out = false;   // d_out holds this rank's LOCAL {Ψ, acc}, not the market's: nothing may be read from it
+            return rc;
+        }
+    }
     return CFMM_OK;
 }
 

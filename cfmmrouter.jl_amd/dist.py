@@ -102,7 +102,10 @@ def join_library_rccl(ctx, group, device):
     """Puts `ctx` into sharded operation through the LIBRARY's RCCL entry points (include/cfmm_amd.h: cfmm_rccl_unique_id /
     cfmm_rccl_init_rank): behind every sweep's fold the library itself enqueues ncclAllReduce(n_tokens + 1 doubles) on the
     context's stream -- north_star's collective, with no torch in the evaluation loop (torch.distributed only carries the
-    128-byte id here, as any launcher's channel would).  Collective: True on ALL ranks or False on all ranks."""
+    128-byte id here, as any launcher's channel would).  Collective: True on ALL ranks or False on all ranks.
+    Failure semantics are RCCL's (include/cfmm_amd.h): no PeerGuard, no vote, no time limit of the library's own -- a rank
+    that dies between two evaluations leaves the others in their stream synchronisation until the launcher's watchdog
+    (torchrun's, NCCL_ASYNC_ERROR_HANDLING) tears the job down.  The peer exchange (tried first) bounds that case itself."""
     import torch
     import torch.distributed as dist
 

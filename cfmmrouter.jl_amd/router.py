@@ -118,9 +118,16 @@ class HostSegment:
         self.Δs = [np.zeros(ai.size) for ai in self.Ai0]      # zerotrade(c), src/router.jl:23-26
         self.Λs = [np.zeros(ai.size) for ai in self.Ai0]
 
-    def sweep(self, v):
+        self._sΔ = [np.zeros(ai.size) for ai in self.Ai0]     # scratch trades of non-materialising evaluations
+        self._sΛ = [np.zeros(ai.size) for ai in self.Ai0]
+
+    def sweep(self, v, materialize=True):
+        """materialize=False (a bare evaluation: the device half writes no trades either): the pools' find_arb_ runs into
+        scratch vectors, so self.Δs / self.Λs stay those of the latest find_arb -- the same price vector as the device
+        pools' trades (the reference overwrites ALL pools' trades in every evaluation; here NONE move between find_arb!s)."""
         psi, acc = np.zeros(self.n_tokens), 0.0
-        for c, ai, D, L in zip(self.pools, self.Ai0, self.Δs, self.Λs):
+        Ds, Ls = (self.Δs, self.Λs) if materialize else (self._sΔ, self._sΛ)
+        for c, ai, D, L in zip(self.pools, self.Ai0, Ds, Ls):
             vl = v[ai]                                   # v[r.cfmms[i].Ai]
             c.find_arb_(D, L, vl)                        # the user's method: overwrites Δ, Λ
             acc += float(np.dot(L, vl) - np.dot(D, vl))  # src/router.jl:82
@@ -136,16 +143,16 @@ class MixedBackend:
         self.inner, self.host = inner, host
         self.n_tokens = host.n_tokens
 
-    def _add(self, res, v):
+    def _add(self, res, v, materialize):
         psi, acc = res
-        ph, ah = self.host.sweep(np.asarray(v, dtype=np.float64))
+        ph, ah = self.host.sweep(np.asarray(v, dtype=np.float64), materialize)
         return psi + ph, acc + ah
 
     def eval(self, v):
-        return self._add(self.inner.eval(v), v)
+        return self._add(self.inner.eval(v), v, False)
 
     def find_arb(self, v):
-        return self._add(self.inner.find_arb(v), v)
+        return self._add(self.inner.find_arb(v), v, True)
 
     def trades(self, out=None):
         return self.inner.trades() if out is None else self.inner.trades(out)
@@ -529,14 +536,23 @@ def update_reserves_(r: Router, sync_host=True):
         for c in r._host.pools:
             if not callable(getattr(c, "update_reserves_", None)):
                 raise ArgumentError(f"{type(c).__name__} has no update_reserves_(Δ, Λ, v) method (src/router.jl:129)")
+
+    def host_pools():
+        # AFTER the device half (which can still refuse: no trades, a UniV3 segment without host prices) -- a refused
+        # update then leaves every pool, host-evaluated ones included, as it was
+        if r._host is None:
+            return
         for c, ai, D, L in zip(r._host.pools, r._host.Ai0, r._host.Δs, r._host.Λs):
             c.update_reserves_(D, L, r.v[ai])
             D[:] = 0.0
             L[:] = 0.0
+
     ctx = getattr(r._backend, "ctx", None)
     if ctx is None:   # test-injected / sharded backends: host-side update of the two-coin families
-        return _update_reserves_host(r)
+        _update_reserves_host(r)
+        return host_pools()
     ctx.update_reserves()
+    host_pools()
     if sync_host:
         seg = 0
         for b in r._batches:
@@ -568,7 +584,7 @@ def update_reserves_(r: Router, sync_host=True):
 def _update_reserves_host(r: Router):
     if any(b.kind == KIND_UNIV3 for b in r._batches):
         raise NotImplementedError("update_reserves! is not defined for UniV3 pools (nor in the reference)")
-    if not hasattr(r._backend, "reload"):
+    if not hasattr(getattr(r._backend, "inner", r._backend), "reload"):    # (MixedBackend forwards to its inner backend)
         raise NotImplementedError("this backend cannot reload pools")
     D, Lm = r._backend.trades()                       # packed (segment) order
     off = 0

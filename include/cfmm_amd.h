@@ -269,8 +269,17 @@ int cfmm_peer_buffer_free(cfmm_ctx* ctx, uint64_t d_buf);
  * cfmm_route relies on it), but not the rank-ordered sum of cfmm_set_peers.  cfmm_set_peers (fold + exchange in ONE
  * launch: no second launch on the critical path of an evaluation) stays the fast path; this is the portable one
  * (cfmmrouter.jl_amd/dist.py tries the peer exchange first, then this, then torch.distributed).  One exchange at a time per context (CFMM_ERR_STATE otherwise);
- * evaluations are launched when their prices are ready (no pre-arming); n_tokens <= 8192.  RCCL is resolved at first use
- * (the process's own RCCL if it has one loaded globally, else librccl.so.1): CFMM_ERR_UNSUPPORTED if there is none. */
+ * evaluations are launched when their prices are ready (no pre-arming); n_tokens <= 8192.  RCCL is resolved at first use,
+ * ALL entry points from ONE image: the one named by CFMM_AMD_RCCL_LIB (environment; path or soname), else the process's
+ * global scope if ncclAllReduce is visible there, else librccl.so.1 -- CFMM_ERR_UNSUPPORTED if there is none.
+ * cfmm_set_rccl_comm takes a foreign communicator only in the first two cases (the caller's own RCCL: a communicator must
+ * meet the ncclAllReduce of the image that created it); cfmm_rccl_init_rank works in all three.
+ * Failure semantics: RCCL's, not cfmm_set_peers'.  The all-reduce has NO time limit of its own -- a rank that fails before
+ * it enqueues its ncclAllReduce (a launch error, an exception between two evaluations of a host-driven loop) leaves the
+ * other ranks waiting in their stream synchronisation, exactly like any NCCL program; bound it with RCCL's own watchdog /
+ * ncclCommAbort from the launcher, or use cfmm_set_peers, whose waits are bounded (CFMM_AMD_PEER_TIMEOUT_S).  A sweep whose
+ * all-reduce could not be enqueued returns the error AFTER its local sweep and fold were launched: trades of a materialising
+ * sweep exist, {psi, acc} do not (cfmm_netflows: CFMM_ERR_STATE). */
 #define CFMM_RCCL_ID_BYTES 128
 int cfmm_rccl_unique_id(unsigned char id[CFMM_RCCL_ID_BYTES]);
 int cfmm_rccl_init_rank(cfmm_ctx* ctx, const unsigned char id[CFMM_RCCL_ID_BYTES], int32_t world, int32_t rank);

@@ -27,6 +27,30 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_unresolvable_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r5 (abi_rccl.cpp): a host without a loadable RCCL gets CFMM_ERR_UNSUPPORTED and a message -- round 5 built
+    the message from TWO dlerror() calls, the second of which returns NULL (std::string + nullptr: SIGSEGV), so the probe
+    dist.join_library_rccl makes on every rank would have killed the process instead of falling back.  CFMM_AMD_RCCL_LIB
+    names the one image RCCL is resolved from; resolution happens once per process, hence a child process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        f"L = ctypes.CDLL({LIB_PATH!r})\n"
+        "L.cfmm_last_error.restype = ctypes.c_char_p\n"
+        "L.cfmm_last_error.argtypes = [ctypes.c_void_p]\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = L.cfmm_rccl_unique_id(buf)\n"
+        "rc2 = L.cfmm_rccl_unique_id(buf)\n"
+        "print(rc, rc2, L.cfmm_last_error(None).decode())\n")
+    env = dict(os.environ, CFMM_AMD_RCCL_LIB="/nonexistent/librccl_absent.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr[-400:])
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == -4 and int(rc2) == -4                      # CFMM_ERR_UNSUPPORTED, again on the second call
+    assert "RCCL is not available" in msg and "librccl_absent" in msg, msg
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():

@@ -119,6 +119,41 @@ def test_a_pool_without_find_arb_is_rejected_and_update_reserves_needs_the_metho
         cr.update_reserves_(r)
 
 
+def test_bare_evaluations_leave_host_pool_trades_at_the_find_arb_prices():
+    """ADVICE r5 (router.py MixedBackend): an evaluation that materialises nothing on the device (dual_jacobian, polish_, the
+    solver's fn/g! calls) must not move the host pools' Δ/Λ either -- r.Δs / r.Λs then all belong to ONE price vector, the
+    latest find_arb!'s, and update_reserves! applies consistent trades.  A refused device update leaves host pools alone."""
+    n = 8
+    b, mixed, host_at = market(n, 200, 6, seed=9)
+    dev_only = [c for c in mixed if c.kind == KIND_PRODUCT]
+    r = cr.Router(cr.LinearNonnegative(0.1 * np.ones(n)), mixed, n,
+                  _backend=OracleBackend(n, [cr.PoolBatch.from_pools(KIND_PRODUCT, dev_only)], nthreads=1))
+    v = synth.sweep_prices(n, seed=5, spread=0.3)
+    cr.find_arb_(r, v)
+    before = [(np.array(r._host.Δs[k]), np.array(r._host.Λs[k])) for k in range(len(host_at))]
+    assert any(np.any(d != 0) for d, _ in before)
+    r._backend.eval(v * np.linspace(0.5, 1.5, n))          # a bare evaluation at other prices
+    r.v[:] = v
+    cr.dual_jacobian(r)
+    for k, (d, l) in enumerate(before):
+        assert np.array_equal(r._host.Δs[k], d) and np.array_equal(r._host.Λs[k], l)
+    # the device half refuses (this backend cannot reload): the host pools' reserves and trades are untouched
+    R0 = [np.array(c.R) for c in r._host.pools]
+    inner = r._backend.inner
+
+    class NoReload:
+        n_tokens = n
+        eval, find_arb, trades = inner.eval, inner.find_arb, inner.trades
+
+    r._backend.inner = NoReload()
+    with pytest.raises(NotImplementedError):
+        cr.update_reserves_(r)
+    for c, R in zip(r._host.pools, R0):
+        assert np.array_equal(c.R, R)
+    for k, (d, l) in enumerate(before):
+        assert np.array_equal(r._host.Δs[k], d)
+
+
 @pytest.mark.gpu
 def test_user_defined_pool_type_mixed_into_a_device_router():
     """a user-defined CFMM subclass mixed into a 10k-pool router -- fixed v <= 1e-12, route! <= 1e-6
