@@ -216,7 +216,10 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
         {"fast_math", &c->opt_fast_math}, {"armed", &c->opt_armed}, {"arm_timeout_ms", &c->opt_arm_timeout_ms},
         {"cost_geomean", &c->opt_cost_geomean}, {"cost_univ3", &c->opt_cost_univ3}, {"host_flag", &c->opt_host_flag},
         {"stop_in_noise", &c->opt_stop_in_noise}, {"multi_threads", &c->opt_multi_threads},
-        {"debug_stall_ms", &c->opt_debug_stall_ms}, {"debug_dev_trust", &c->opt_debug_dev_trust}, {"univ3_heads", &c->opt_univ3_heads},
+        {"dev_prices_in_window", &c->opt_dev_prices_in_window}, {"univ3_heads", &c->opt_univ3_heads},
+#ifdef CFMM_TEST_HOOKS
+        {"debug_stall_ms", &c->opt_debug_stall_ms},
+#endif
     };
     for (auto& t : table)
         if (!std::strcmp(key, t.name)) return t.slot;

@@ -373,7 +373,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         // ... which the host knows for host-pointer sweeps and cfmm_route (pre-armed launches: armed_eval checks the prices before
         // it signals and cancels a launch whose prices turn out to be outside); a device-pointer sweep (prices unknown) gets the
         // kernel that carries both loops and decides per block from the prices it stages
-        const int arith = !fast ? 0 : (price_window == kPricesUnknown && arm_seq == 0 && c->opt_debug_dev_trust == 0) ? 2 : 1;
+        const int arith = !fast ? 0 : (price_window == kPricesUnknown && arm_seq == 0 && c->opt_dev_prices_in_window == 0) ? 2 : 1;
         const auto gbase_of = [&](const Segment& s) { return a.gtab_n ? s.gbase : -1; };   // -1: fees from the gamma array
         auto product_of = [&](const Segment& s) { return ProductPools{s.R, s.gamma, s.Ai, s.pk, gbase_of(s)}; };
         auto geomean_of = [&](const Segment& s) {
@@ -796,10 +796,12 @@ int armed_eval(cfmm_ctx* c, const double* v, bool* lost_out)
         if (lost_out) *lost_out = true;
         return is_parent(c) ? multi_host_sweep(c, v, false) : single_host_sweep(c, v, false);
     }
+#ifdef CFMM_TEST_HOOKS
     if (c->opt_debug_stall_ms > 0 && c->arm_pending) {   // test hook: the host "stalls" once while a launch waits for its prices
         std::this_thread::sleep_for(std::chrono::milliseconds(c->opt_debug_stall_ms));
         c->opt_debug_stall_ms = 0;
     }
+#endif
     if (!is_parent(c)) {
         uint64_t want = 0;
         bool signalled = false;

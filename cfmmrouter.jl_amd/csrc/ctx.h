@@ -199,9 +199,12 @@ struct cfmm_ctx {
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
     int64_t opt_univ3_heads = 1;   // 1: multi-tick UniV3 walks decide their first four list ticks from the per-pool float threshold heads
-    int64_t opt_debug_dev_trust = 0; // A/B hook: 1 = device-pointer sweeps launch the fast kernels on trust (round 4's behaviour: a price
-                                     //    outside the window poisons the output) instead of the kernels that carry both arithmetics
-    int64_t opt_debug_stall_ms = 0; // test hook: the next armed evaluation is preceded by a host stall of this length (once)
+    int64_t opt_dev_prices_in_window = 0; // 1 = the CALLER vouches that the prices of device-pointer sweeps lie in [2^-kFastExp, 2^kFastExp]
+                                     //    (what the host checks itself for host-pointer calls): cfmm_sweep_dev launches the fast kernels
+                                     //    instead of the ones that carry both arithmetics; every block still checks what it stages and
+                                     //    poisons its row (NaN in {psi, acc}: an error, never a wrong number) when the promise is broken
+    int64_t opt_debug_stall_ms = 0; // test hook, reachable only in libcfmm_amd_hooks.so (-DCFMM_TEST_HOOKS: the option key and the stall
+                                    //    exist there alone; the FIELD is unconditional so that every translation unit sees one layout)
     uint64_t sweep_count = 0;
 
     // kernel timing

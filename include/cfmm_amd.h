@@ -104,7 +104,12 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     also evaluates its exponential with an own < 1 ulp polynomial instead of the device library's;
  *                     anything outside the window runs the full-range arithmetic -- device-pointer sweeps, whose prices
  *                     the library cannot see, decide per block inside the launch (cfmm_sweep_dev);
- *                     0: the compiler's sequences and the library's exp everywhere), "geomean_exact" (1 = GeometricMeanTwoCoin
+ *                     0: the compiler's sequences and the library's exp everywhere), "dev_prices_in_window" (default 0;
+ *                     1 = the caller vouches that the prices it passes to cfmm_sweep_dev lie in [2^-150, 2^150] -- the
+ *                     check the library makes itself on host-pointer calls -- and device-pointer sweeps launch the fast
+ *                     kernels alone (fewer registers than the kernels that carry both arithmetics); every block still
+ *                     checks the prices it stages, and a broken promise yields NaN in every entry of {psi, acc}: an
+ *                     error, never a wrong number), "geomean_exact" (1 = GeometricMeanTwoCoin
  *                     with pow in the reference's operation order instead of the default log-space form; both are within
  *                     1e-12 of the reference), "alternate" (default 1: consecutive evaluations walk every lane's tiles in
  *                     alternating directions, so that a sweep starts on the pool data the previous one left in the XCD's
@@ -332,8 +337,9 @@ int cfmm_segment_info(const cfmm_ctx* ctx, int32_t seg, int32_t* kind, int64_t* 
  * update_reserves!, the objectives) and what sharding them needs.  What follows is NOT in CFMMRouter.jl, may change, and
  * is not needed to replace the reference's path:
  *   - cfmm_polish (below),
- *   - the option "stop_in_noise" (cfmm_set_option; default 0 = the stopping rules of L-BFGS-B 3.0),
- *   - the test / A-B hooks "debug_stall_ms", "debug_dev_trust".
+ *   - the option "stop_in_noise" (cfmm_set_option; default 0 = the stopping rules of L-BFGS-B 3.0).
+ * (Test hooks are not in this library: `make -C cfmmrouter.jl_amd/csrc hooks` builds libcfmm_amd_hooks.so with
+ * -DCFMM_TEST_HOOKS for tests/test_gpu_armed.py.)
  * ====================================================================================================================== */
 
 /* Tighten a route!'s result beyond what L-BFGS-B's stopping rules can (NOT part of the reference: its route! ends where

@@ -146,10 +146,9 @@ def test_route_on_a_multi_device_parent_armed_or_not(devices):
         np.testing.assert_array_equal(a, b)
 
 
-def test_a_lost_hand_over_costs_a_retry_not_the_route():
-    """ADVICE r2: a host that stalls longer than arm_timeout_ms between two evaluations (debugger, SIGSTOP,
-    oversubscription) makes the waiting launch give up; the evaluation is then repeated through the launch-when-ready
-    path and the rest of the call runs unarmed -- same result, no error.  (debug_stall_ms: the stall, injected once.)"""
+def lost_hand_over_body():
+    """Body of test_a_lost_hand_over_costs_a_retry_not_the_route: runs in a child process that has loaded
+    libcfmm_amd_hooks.so (the only build that knows the option "debug_stall_ms")."""
     n = 48
     batches = [synth.product_pools(80_000, n, seed=31), synth.geomean_pools(20_000, n, seed=32)]
     c = synth.linear_prices(n, seed=5)
@@ -168,6 +167,35 @@ def test_a_lost_hand_over_costs_a_retry_not_the_route():
         np.testing.assert_array_equal(v, ref[0])
     finally:
         be.close()
+
+
+def test_a_lost_hand_over_costs_a_retry_not_the_route():
+    """ADVICE r2: a host that stalls longer than arm_timeout_ms between two evaluations (debugger, SIGSTOP,
+    oversubscription) makes the waiting launch give up; the evaluation is then repeated through the launch-when-ready
+    path and the rest of the call runs unarmed -- same result, no error.  The stall is injected by the test hook
+    "debug_stall_ms", which the shipped library does not contain: the body runs in a child process on
+    libcfmm_amd_hooks.so (`make -C cfmmrouter.jl_amd/csrc hooks`; same objects, two host files rebuilt with
+    -DCFMM_TEST_HOOKS)."""
+    import os
+    import subprocess
+    import sys
+    from cfmmrouter_amd._lib import LIB_PATH
+    be = cr.DeviceBackend(4, [synth.product_pools(10, 4, seed=1)])
+    try:
+        with pytest.raises(Exception, match="unknown option"):
+            be.ctx.set_option("debug_stall_ms", 1)                                    # not in the shipped library
+    finally:
+        be.close()
+    hooks = os.path.join(os.path.dirname(LIB_PATH), "libcfmm_amd_hooks.so")
+    assert os.path.exists(hooks), "build it: make -C cfmmrouter.jl_amd/csrc hooks (__graft_entry__.build() does)"
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import test_gpu_armed as t\n"
+            "t.lost_hand_over_body()\n"
+            "print('hooks-ok')\n") % (os.path.dirname(here), here)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFMM_AMD_LIB=hooks), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "hooks-ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
 def test_stop_in_noise_is_an_option_and_off_by_default():

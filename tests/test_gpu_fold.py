@@ -308,8 +308,8 @@ def test_fast_math_price_window_is_checked_by_host_and_by_every_block(vscale):
     restatement.  Device-pointer sweeps (cfmm_sweep_dev: prices the library cannot see) launch the kernels that carry BOTH
     arithmetics and every block picks from the prices it stages (round 5): the SAME exact result, CFMM_OK, no state change --
     round 4 launched the fast kernels on trust, delivered NaN and reported it on a later call.  The
-    blocks' own check of a FAST kernel is still there (debug_dev_trust = 1: the fast kernel refuses such prices: all NaN,
-    never a wrong number)."""
+    blocks' own check of a FAST kernel is still there (dev_prices_in_window = 1, the caller's promise that its device prices
+    are inside the window, broken here: the fast kernel refuses such prices -- all NaN, never a wrong number)."""
     import torch
     n = 64
     batches = [synth.product_pools(80_000, n, seed=611), synth.univ3_pools(9_000, n, 4, seed=612)]
@@ -334,12 +334,12 @@ def test_fast_math_price_window_is_checked_by_host_and_by_every_block(vscale):
             assert np.all(np.isfinite(ot.cpu().numpy()))
             res[fast] = (ot.cpu().numpy(),) + be.trades()
             if fast and vscale != 1.0:
-                be.ctx.set_option("debug_dev_trust", 1)               # the fast kernel alone: its blocks refuse these prices
+                be.ctx.set_option("dev_prices_in_window", 1)          # a broken promise: the fast kernel alone, its blocks refuse these prices
                 o2 = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
                 be.ctx.sweep_dev(vt.data_ptr(), o2.data_ptr(), False)
                 torch.cuda.synchronize()
                 assert np.all(np.isnan(o2.cpu().numpy()))
-                be.ctx.set_option("debug_dev_trust", 0)
+                be.ctx.set_option("dev_prices_in_window", 0)
                 psi_h2, _ = be.eval(v)                                 # ... and the stale report does not taint a host-pointer call
                 assert rel_to_max(psi_h2, psi_o) <= 1e-12
             v_in = synth.sweep_prices(n, seed=614)                     # and prices inside the window keep working

@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_shipped_library_carries_no_test_hooks():
+    """the test hook "debug_stall_ms" exists only in libcfmm_amd_hooks.so (-DCFMM_TEST_HOOKS), and the
+    header documents no debug keys."""
+    blob = open(LIB_PATH, "rb").read()
+    assert b"debug_stall_ms" not in blob and b"debug_dev_trust" not in blob
+    hdr = open(os.path.join(ROOT, "include", "cfmm_amd.h")).read()
+    assert not re.findall(r'"debug_[a-z_]+"', hdr.split("EXPERIMENTAL")[0])
+    hooks = os.path.join(os.path.dirname(LIB_PATH), "libcfmm_amd_hooks.so")
+    if os.path.exists(hooks):
+        assert b"debug_stall_ms" in open(hooks, "rb").read()
+
+
 def test_unresolvable_rccl_is_an_error_code_not_a_crash():
     """ADVICE r5 (abi_rccl.cpp): a host without a loadable RCCL gets CFMM_ERR_UNSUPPORTED and a message -- round 5 built
     the message from TWO dlerror() calls, the second of which returns NULL (std::string + nullptr: SIGSEGV), so the probe
