@@ -1,6 +1,7 @@
 """Pins the OUTER LOOP of route! to the solver lineage the reference actually calls.
 
     /opt/conda/bin/python3.9 tests/golden/make_route_golden.py        # -> tests/golden/route_fortran.npz
+    /opt/conda/bin/python3.9 tests/golden/make_route_golden.py --only full_config4 --merge   # add / refresh one market
 
 The reference's route! (src/router.jl:58-108) hands its dual problem to LBFGSB.jl (src/router.jl:60,105), a `ccall`
 wrapper of the FORTRAN L-BFGS-B 3.0 `setulb` in a reverse-communication loop, with the call shape
@@ -80,7 +81,9 @@ def all_markets(only=()):
            cr.BasketLiquidation(1, synth.basket(n, seed=1234)), None)
     # the bench's workloads at BASELINE size (benchlib/workloads.py: the markets bench.py and the GPU tests build)
     from benchlib.workloads import WORKLOADS, build_market, objective_for
-    for name in ("config2", "config3", "config4shard", "config5", "product1m", "univ3_ticks"):
+    # "config4" = BASELINE config 4 at its stated size: ALL 4M ProductTwoCoin pools, 512 tokens (round 6; the pool order is
+    # the global one: shard after shard of the 8-GPU split)
+    for name in ("config2", "config3", "config4shard", "config5", "product1m", "univ3_ticks", "config4"):
         if only and "full_" + name not in only:
             continue
         n = WORKLOADS[name][1]
@@ -174,9 +177,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="comma-separated market names (default: all)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "route_fortran.npz"))
+    ap.add_argument("--merge", action="store_true", help="keep the markets already in --out that are not regenerated (--only)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     out = {"scipy_version": np.array(scipy.__version__), "keep": np.array(KEEP)}
+    if args.merge and os.path.exists(args.out):
+        old = np.load(args.out)
+        assert str(old["scipy_version"]) == scipy.__version__, "merge into a fixture of another SciPy build"
+        out.update({k: old[k] for k in old.files})
     for name, batches, n, obj, v0 in markets(only):
         r = route_fortran(obj, batches, n, v0)
         r["xs"] = r["xs"][:KEEP_FULL if name.startswith("full_") else KEEP]

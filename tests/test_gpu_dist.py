@@ -133,6 +133,27 @@ def test_sharded_route_across_processes_sharing_one_gpu(world):
     assert out["route_native_rel_diff"] <= 1e-6 and out["route_scipy_rel_diff"] <= 1e-6 and out["evaluations"] >= 5
 
 
+def test_config4_at_full_size_across_eight_processes_sharing_one_gpu():
+    """VERDICT r5 item 2 / BASELINE config 4 AT ITS STATED SIZE: 4M ProductTwoCoin pools, 512 tokens, 8 shards of 500k pools
+    -- here 8 PROCESSES on the one GPU (gloo rendezvous, the library's IPC peer buffers, fold + gather in one launch: the
+    N = 8 path minus the xGMI links).  Every rank: all 500k trade rows of its shard bit-equal to the CPU restatement at
+    fixed prices; rank 0: the global Ψ <= 1e-12 of the serial pool-order sum, ranks bit-identical, and route! within
+    north_star's 1e-6 of the Fortran L-BFGS-B 3.0 run on the restatement of the SAME 4M-pool market
+    (tests/golden/route_fortran.npz: full_config4; that run's own pool-order slack is 8e-7)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ipc_ranks_worker.py"), "--config4"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CFMM_AMD_PEER_TIMEOUT_S="30")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("IPC_RANKS ")][-1][len("IPC_RANKS "):])
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ipc_ranks_config4_world8.json"), "w"), indent=1)
+    assert out["world"] == 8 and out["pools_total"] == 4_000_000 and out["in_library_collective"]
+    assert out["all_trade_rows_bit_equal"] and out["ranks_bit_identical"]
+    assert out["fixed_v_rel_err_vs_oracle"] <= 1e-12
+    assert out["route_native_vs_fortran"] <= 1e-6 and out["route_scipy_vs_fortran"] <= 1e-6 and out["evaluations"] >= 5
+
+
 @pytest.mark.parametrize("mode", ["selftest-fail", "fail-route-once"])
 def test_sharded_router_guard_across_processes(mode):
     """VERDICT r3 item 3, in the LIBRARY path (dist.py::ShardedRouter), two processes on the one GPU:

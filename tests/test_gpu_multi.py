@@ -90,6 +90,42 @@ def test_config4_shape_eight_shards_route_parity():
         r1.close()
 
 
+def test_config4_at_full_size_eight_shards():
+    """VERDICT r5 item 2 / BASELINE config 4 AT ITS STATED SIZE (4M ProductTwoCoin pools, 512 tokens, 8 shards of 500k --
+    /root/reference/src/router.jl:38-42 over 4M pools, :111-119) through ONE multi-device context with the device listed 8
+    times: all 4M trade rows bit-equal to the CPU restatement at fixed prices, Ψ and the dual value <= 1e-12, and route!
+    (one cfmm_route call driving the 8 shards) within north_star's 1e-6 of the Fortran L-BFGS-B 3.0 run on the restatement
+    of this market (tests/golden/route_fortran.npz: full_config4)."""
+    from benchlib.workloads import build_market, objective_for, sweep_prices_for
+    n = 512
+    batches = build_market("config4", 0, 1, "weak")
+    assert sum(len(b) for b in batches) == 4_000_000
+    obj = objective_for("config4", n)
+    v = sweep_prices_for("config4", n)
+    threads = orc.lib().oracle_max_threads()
+    r8 = cr.Router(obj, batches, n, device=[0] * 8)
+    try:
+        assert r8._backend.ctx.device_count == 8
+        cr.find_arb_(r8, v)
+        D, L, psi_o, acc_o = oracle_sweep(batches, n, v, nthreads=threads)
+        np.testing.assert_array_equal(r8.Δs, D)                   # 4M rows, bit for bit
+        np.testing.assert_array_equal(r8.Λs, L)
+        assert rel_to_max(cr.netflows(r8), psi_o) <= 1e-12 and abs(r8._acc - acc_o) <= 1e-12 * abs(acc_o)
+        del D, L
+        cr.route_(r8, v=np.ones(n), solver="native")
+        g = np.load(os.path.join(ROOT, "tests", "golden", "route_fortran.npz"))
+        psi_f = g["full_config4_psi"]
+        gap = float(np.max(np.abs(cr.netflows(r8) - psi_f)) / np.max(np.abs(psi_f)))
+        print(f"config 4 (4M pools, 8 shards): route! vs Fortran L-BFGS-B {gap:.2e} (that run's pool-order slack "
+              f"{float(g['full_config4_slack']):.2e}), {r8.info['funcalls']} evaluations (Fortran {int(g['full_config4_evaluations'])})")
+        assert gap <= 1e-6 and r8.info["funcalls"] >= 5
+        D, L, _, _ = oracle_sweep(batches, n, r8.v, nthreads=threads)   # trades at v*: the reference's find_arb!(r, v*)
+        np.testing.assert_array_equal(r8.Δs, D)
+        np.testing.assert_array_equal(r8.Λs, L)
+    finally:
+        r8.close()
+
+
 def test_polish_on_a_multi_device_parent_equals_the_single_device_polish():
     """cfmm_polish drives a multi-device parent like cfmm_route does (host-pointer sweeps over all shards): from the same
     route! both reach the same converged point as one device."""
