@@ -70,7 +70,7 @@ import torch.distributed as dist
 
 import cfmmrouter_amd as cr
 from benchlib.legs import finish_route, host_boundary_leg, roofline_record, route_leg, single_process_main
-from benchlib.shard import ShardBench, sharded_route
+from benchlib.shard import ShardBench, collectives_leg, sharded_route
 from benchlib.traffic import live_traffic
 from benchlib.workloads import METRIC, WORKLOADS, build_global, objective_for   # noqa: F401  (scripts import WORKLOADS from here)
 
@@ -411,7 +411,12 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 PMC passes of this command (two bounded child runs); "
                          "use the committed profiles/traffic.json")
-    ap.add_argument("--rccl", action="store_true", help="force the RCCL all-reduce instead of the one-shot peer gather")
+    ap.add_argument("--collective", default="auto", choices=["auto", "peer", "rccl_library", "rccl_torch"],
+                    help="N > 1: the all-reduce of {Psi, acc} the HEADLINE step uses (auto = the first that works of: the library's "
+                         "one-launch peer gather, ncclAllReduce inside the library, torch.distributed); all three are timed side by "
+                         "side under `collectives` whatever is chosen here")
+    ap.add_argument("--rccl", action="store_true", help="alias of --collective rccl_library (north_star's collective as the headline)")
+    ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the side-by-side `collectives` block")
     ap.add_argument("--cold-only", action="store_true",
                     help="the timed region rotates over > 300 MB of market copies (pool state from HBM, not the Infinity "
                          "Cache): used for the rocprofv3 summary of the HBM-resident figure")
@@ -421,6 +426,8 @@ def main():
     ap.add_argument("--devices", default="", help="--single-process: comma-separated HIP ordinals (default 0..N-1; an "
                                                   "ordinal may repeat to put several shards on one GPU)")
     args = ap.parse_args()
+    if args.rccl:
+        args.collective = "rccl_library"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -541,6 +548,34 @@ def main():
             1e3 * cold["ms_per_step"], 1e3 * cold["kernel_ms"], cold["frac"], cold["copies"], cold["bytes_touched"] / 1e6)
     if collective_check is not None:
         line["collective_check_rel_err"] = collective_check
+        line["collective"] = {"headline": sb.collective, "requested": args.collective,
+                              **({"requested_unavailable": sb.why_not} if sb.why_not else {}),
+                              **({"auto_fell_back_because": sb.fell_back} if getattr(sb, "fell_back", None) else {})}
+    if use_dist and not args.no_collectives:
+        # the same step under all three all-reduces, side by side (one run answers which collective the curve should use)
+        try:
+            line["collectives"] = collectives_leg(args, args.workload, args.scaling, rank, world, local_rank, sb)
+        except Exception as e:
+            line["collectives"] = {"error": repr(e)[:300]}
+        line["collectives_is"] = ("ms_per_step of the SAME step (K steps between barrier + synchronize, max over ranks) under each all-reduce "
+                                  "of the n_tokens+1 doubles: peer = cfmm_set_peers (fold + xGMI gather in one launch), rccl_library = "
+                                  "ncclAllReduce enqueued by the library behind the fold (cfmm_rccl_init_rank; north_star's collective), "
+                                  "rccl_torch = torch.distributed.all_reduce on the sweep's stream; kernel_ms_min/max = the sweep kernel's "
+                                  "mean span on the fastest / slowest rank; `value` of the line is the `collective.headline` one")
+        if world == 1:
+            # N = 1 under torchrun against the plain N = 1 step in the SAME process (same box, same clocks): the sharded
+            # machinery at world 1 (fold + gather launch with one rank) must cost nothing
+            try:
+                plain = ShardBench(args, args.workload, args.scaling, 0, 1, local_rank, False)
+                for _ in range(args.warmup):
+                    plain.step()
+                e1, _ = plain.timed_pass(args.steps)
+                plain.close()
+                torch.cuda.set_stream(sb.stream)
+                line["plain_n1"] = {"ms_per_step": 1e3 * e1 / args.steps, "ratio_torchrun_over_plain": ms_per_step / (1e3 * e1 / args.steps),
+                                    "is": "the same K steps on a plain single-GPU context (no process group) in this process"}
+            except Exception as e:
+                line["plain_n1"] = {"error": repr(e)[:200]}
     if route_sharded is not None:
         line["route_sharded"] = route_sharded
     if host:
@@ -558,7 +593,10 @@ def main():
             chk = s4.collective_check()
             line["strong_scaling"] = {"workload": "config4: " + s4.desc, "pools_total": 4_000_000, "pools_per_gpu": s4.m_rank,
                                       "ms_per_step": 1e3 * e4 / args.steps, "value": 4_000_000 * args.steps / e4, "unit": "pools/s",
-                                      "scaling": "strong", "sharding": s4.sharding_text(), "collective_check_rel_err": chk}
+                                      "scaling": "strong", "sharding": s4.sharding_text(), "collective": s4.collective,
+                                      "collective_check_rel_err": chk}
+            if not args.no_collectives:
+                line["strong_scaling"]["collectives"] = collectives_leg(args, "config4", "strong", rank, world, local_rank, s4)
             s4.close()
         except Exception as e:
             line["strong_scaling"] = {"error": repr(e)[:300]}

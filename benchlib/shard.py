@@ -16,7 +16,14 @@ from .workloads import (HBM_PEAK_GBS, L3_BYTES, WORKLOADS, alg_bytes, build_mark
 class ShardBench:
     """One rank's timed machinery for one workload: backend, stream, peer buffers (N > 1), the step."""
 
-    def __init__(self, args, name, scaling, rank, world, local_rank, use_dist):
+    def __init__(self, args, name, scaling, rank, world, local_rank, use_dist, collective=None):
+        """collective (sharded runs): which all-reduce of {Ψ, acc} the step uses --
+             "peer"          the library's fold + one-shot xGMI peer gather in ONE launch (cfmm_set_peers),
+             "rccl_library"  ncclAllReduce enqueued by the library behind every fold (cfmm_rccl_init_rank): north_star's collective,
+             "rccl_torch"    torch.distributed.all_reduce on the sweep's stream (RCCL; gloo in the shared-GPU rehearsal),
+             "auto"          the first of those three that works on THIS machine (every choice is a collective vote);
+           None = args.collective.  `self.collective` says which one the steps use, `self.why_not` why an explicitly requested
+           one is not available (the steps then fall back to rccl_torch so that no rank is left alone)."""
         self.args, self.name, self.rank, self.world, self.use_dist = args, name, rank, world, use_dist
         self.desc, self.n, _ = WORKLOADS[name]
         n = self.n
@@ -36,13 +43,32 @@ class ShardBench:
         self.steps_run = 0
         self.ring, self.ring_pos = None, 0
         self.lib_rccl = False
-        if use_dist and not args.rccl and os.environ.get("CFMM_AMD_NO_PEER", "0") != "1":
-            self.setup_peers()
-        if use_dist and args.rccl and dist.get_backend() == "nccl":
-            # --rccl: the collective through the library's own RCCL entry points (cfmm_rccl_init_rank: ncclAllReduce behind
-            # every fold, on the sweep's stream) -- what a Julia / C host gets; torch.distributed only carries the 128-byte id
-            from cfmmrouter_amd.dist import join_library_rccl
-            self.lib_rccl = join_library_rccl(self.be.ctx, None, torch.device("cuda", local_rank))
+        want = collective or getattr(args, "collective", "auto")
+        self.collective, self.why_not = ("none" if not use_dist else "rccl_torch"), None
+        if use_dist and want in ("auto", "peer"):
+            if os.environ.get("CFMM_AMD_NO_PEER", "0") == "1":
+                self.why_not = "CFMM_AMD_NO_PEER=1"
+            else:
+                self.setup_peers()
+                if self.fused_peer:
+                    self.collective = "peer"
+                elif self.why_not is None:
+                    self.why_not = "no rank-to-rank mapping of the peer buffers (hipIpc) on this machine"
+        if use_dist and self.collective != "peer" and want in ("auto", "rccl_library"):
+            # the collective through the library's own RCCL entry points (cfmm_rccl_init_rank: ncclAllReduce behind every fold,
+            # on the sweep's stream) -- what a Julia / C host gets; torch.distributed only carries the 128-byte id
+            if dist.get_backend() != "nccl":
+                self.why_not = "ranks share a GPU (rehearsal over gloo): RCCL needs one device per rank"
+            else:
+                from cfmmrouter_amd.dist import join_library_rccl
+                self.lib_rccl = join_library_rccl(self.be.ctx, None, torch.device("cuda", local_rank))
+                if self.lib_rccl:
+                    self.collective = "rccl_library"
+                else:
+                    self.why_not = "cfmm_rccl_unique_id / cfmm_rccl_init_rank failed on a rank (collective vote)"
+        self.fell_back = self.why_not if (want == "auto" and self.collective == "rccl_torch") else None   # auto: why the faster two are out
+        if want == "auto" or self.collective == want:
+            self.why_not = None
 
     def apply_options(self, be):
         for kv in self.args.opt:
@@ -59,6 +85,7 @@ class ShardBench:
         self.peer = open_peer_buffers(be.ctx, None, torch.device("cuda", self.local_rank))  # None (on every rank) -> RCCL
         if self.peer is None:
             return
+        self.why_not = "the peer exchange disagreed with torch.distributed's all-reduce in the start-up check (collective vote)"
         self.peer_ptrs = list(self.peer.ptrs)
         good = True
         for _ in range(3):
@@ -77,6 +104,7 @@ class ShardBench:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         self.fused_peer = float(flag.item()) == 1.0
         if self.fused_peer:
+            self.why_not = None
             be.ctx.set_peers(self.peer_ptrs, world, rank, self.n_fused)
 
     def step(self):
@@ -253,7 +281,7 @@ class ShardBench:
         if self.lib_rccl:
             return (f"pools x{self.world}, RCCL all-reduce of n_tokens+1 f64 per step INSIDE the library (cfmm_rccl_init_rank: "
                     f"ncclAllReduce enqueued behind the fold on the sweep's stream)")
-        return f"pools x{self.world}, RCCL all-reduce of n_tokens+1 f64 per step (torch.distributed)"
+        return f"pools x{self.world}, all-reduce of n_tokens+1 f64 per step through torch.distributed ({dist.get_backend()})"
 
     def close(self):
         if self.ring:
@@ -325,3 +353,64 @@ def sharded_route(sb, local_rank):
     return out, psi, v_star, sr, hidden
 
 
+
+
+def collectives_leg(args, name, scaling, rank, world, local_rank, headline):
+    """The SAME step timed under each of the three all-reduces, side by side in one run (the first
+    multi-GPU lease is one shot): `peer` (cfmm_set_peers: fold + xGMI gather in one launch), `rccl_library` (north_star's
+    collective: ncclAllReduce enqueued by the library behind the fold, cfmm_rccl_init_rank) and `rccl_torch`
+    (torch.distributed.all_reduce on the sweep's stream).  Per collective: W warm-up steps, K steps between barrier +
+    synchronize, MAX over ranks; the result against a plain all-reduce of the local {Ψ, acc}; the sweep kernel's mean span on
+    the fastest and the slowest rank.  `headline` (the ShardBench of the timed region) is reused for its own collective.
+    Every decision is a collective vote, so a failure on one rank costs that entry (`ok: false, why_not`), never a hang."""
+    out = {}
+
+    def all_ok(flag):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) == 1.0
+
+    for mode in ("peer", "rccl_library", "rccl_torch"):
+        sb, own, err = None, False, None
+        try:
+            if headline is not None and headline.collective == mode and headline.name == name:
+                sb = headline
+            else:
+                sb, own = ShardBench(args, name, scaling, rank, world, local_rank, True, collective=mode), True
+        except Exception as e:
+            err = repr(e)[:200]
+        if not all_ok(err is None):
+            out[mode] = {"ok": False, "why_not": err or "construction failed on another rank"}
+            if own and sb is not None:
+                sb.close()
+            continue
+        if sb.collective != mode:
+            out[mode] = {"ok": False, "why_not": sb.why_not or "not available"}
+            if own:
+                sb.close()
+            continue
+        rec = {"ok": True}
+        try:
+            for _ in range(args.warmup):
+                sb.step()
+            elapsed, _ = sb.timed_pass(args.steps)
+            elapsed = sb.max_over_ranks(elapsed)
+            kt, _ = sb.kernel_pass(args.steps)
+            k_ms = kt["sweep_ms"] / max(args.steps, 1)
+            ks = torch.tensor([k_ms, -k_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ks, op=dist.ReduceOp.MAX)
+            rec.update(ms_per_step=1e3 * elapsed / args.steps, value=world * sb.m_rank * args.steps / elapsed,
+                       kernel_ms_max=float(ks[0].item()), kernel_ms_min=float(-ks[1].item()),
+                       fold_or_gather_kernel_ms=kt["reduce_ms"] / max(args.steps, 1),
+                       check_rel_err=sb.collective_check(), sharding=sb.sharding_text(),
+                       **({"rccl_ranks": world} if mode != "peer" else {"peer_ranks": world}))
+        except Exception as e:
+            err = repr(e)[:200]
+        if not all_ok(err is None):
+            rec = {"ok": False, "why_not": err or "failed on another rank"}
+        out[mode] = rec
+        if own:
+            sb.close()
+        if headline is not None:
+            torch.cuda.set_stream(headline.stream)
+    return out

@@ -57,6 +57,16 @@ def test_bench_under_torchrun_world1(extra):
     assert ("RCCL" in line["config"]["sharding"]) == bool(extra)
     rs = line["route_sharded"]
     assert "error" not in rs and rs["ranks_agree_on_v"] and rs["evaluations"] >= 5
+    # one line carries the step under ALL three all-reduces, whichever is the headline
+    assert line["collective"]["headline"] == ("rccl_library" if extra else "peer")
+    col = line["collectives"]
+    for mode in ("peer", "rccl_library", "rccl_torch"):
+        assert col[mode]["ok"], (mode, col[mode])
+        assert col[mode]["ms_per_step"] > 0 and col[mode]["check_rel_err"] <= 1e-12
+        assert 0 < col[mode]["kernel_ms_min"] <= col[mode]["kernel_ms_max"]
+    assert col["rccl_library"]["rccl_ranks"] == 1 and "cfmm_rccl_init_rank" in col["rccl_library"]["sharding"]
+    # N = 1 under torchrun costs what the plain N = 1 step costs (same process, same clocks)
+    assert line["plain_n1"]["ratio_torchrun_over_plain"] <= (1.10 if extra else 1.05), line["plain_n1"]
     tag = "rccl" if extra else "peer"
     json.dump(line, open(os.path.join(ROOT, "gpurun_out", f"bench_torchrun_world1_{tag}.json"), "w"), indent=1)
 
@@ -202,6 +212,14 @@ def test_bench_rehearsal_world2_on_one_gpu():
     assert "error" not in rs and rs["ranks_agree_on_v"] and rs["pools_total"] == line["config"]["pools_total"]
     ss = line["strong_scaling"]
     assert ss["pools_total"] == 4_000_000 and ss["pools_per_gpu"] == 2_000_000 and ss["collective_check_rel_err"] <= 1e-12
+    # the `collectives` block: all three keys on the weak and the strong leg; two processes on one GPU can
+    # run the peer exchange and torch.distributed (gloo here), not RCCL -- which says so instead of hanging
+    for col in (line["collectives"], ss["collectives"]):
+        assert set(col) == {"peer", "rccl_library", "rccl_torch"}
+        assert col["peer"]["ok"] and col["peer"]["check_rel_err"] <= 1e-12 and col["peer"]["peer_ranks"] == 2
+        assert col["rccl_torch"]["ok"] and col["rccl_torch"]["check_rel_err"] <= 1e-12
+        assert not col["rccl_library"]["ok"] and "one device per rank" in col["rccl_library"]["why_not"]
+    assert line["collective"]["headline"] == "peer"
     assert line["cpu_baseline"]["value"] > 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(line, open(os.path.join(ROOT, "gpurun_out", "bench_rehearsal_world2.json"), "w"), indent=1)
