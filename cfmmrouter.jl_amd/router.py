@@ -505,16 +505,40 @@ def polish_(r: Router, iters=8, jacobian=None, rel_step=1e-7, native=None):
     return None
 
 
-def netflows_(ψ, r: Router):
-    """netflows!(ψ, r) -- src/router.jl:111-119: ψ = Σᵢ Aᵢ(Λᵢ − Δᵢ) for the latest sweep."""
-    ψ[:] = r._psi
+def netflows_(ψ, r: Router, exact=False):
+    """netflows!(ψ, r) -- src/router.jl:111-119: ψ = Σᵢ Aᵢ(Λᵢ − Δᵢ) for the latest sweep.
+
+    exact=False (default): the device's reduction of the sweep that produced r.Δs / r.Λs (per-wavefront LDS bins, fixed-order
+    folds): within 1e-12·max|ψ| of the reference's value, no per-pool data moved.
+    exact=True: the reference's OWN loop -- `ψ[c.Ai] .+= Λ - Δ` pool after pool in router order (src/router.jl:113-116) --
+    over the fetched trade rows, i.e. bit for bit what `netflows(r)` returns upstream, so that the reference's router test
+    `all_flows .== netflows(r)` (test/arb.jl:16) holds unedited.  O(m) on the host (as upstream), and it fetches r.Δs / r.Λs."""
+    if not exact:
+        ψ[:] = r._psi
+        return None
+    Δs, Λs = r.Δs, r.Λs
+    ψ[:] = 0.0
+    if r._host is not None:                      # per-pool vectors of any length, router order
+        for Δ, Λ, c in zip(Δs, Λs, r.cfmms):
+            ai = np.asarray(c.Ai, dtype=np.int64).reshape(-1) - 1
+            for k in range(ai.size):             # broadcast assignment, element after element
+                ψ[ai[k]] += Λ[k] - Δ[k]
+        return None
+    Ai = np.concatenate([b.Ai for b in r._batches]) if r._batches else np.zeros((0, 2), dtype=np.int64)
+    if r._order is not None:                     # packed (family-grouped) order -> router order
+        Ar = np.empty_like(Ai)
+        Ar[r._order] = Ai
+        Ai = Ar
+    # np.bincount adds its weights to each bin one after another in input order: pool 1 coin 1, pool 1 coin 2, pool 2 coin 1, ...
+    # -- the reference's loop, starting from zeros
+    ψ[:] = np.bincount((Ai.astype(np.int64) - 1).ravel(), weights=(Λs - Δs).ravel(), minlength=r.n_tokens)[:r.n_tokens]
     return None
 
 
-def netflows(r: Router):
-    """netflows(r) -- src/router.jl:121-125"""
+def netflows(r: Router, exact=False):
+    """netflows(r) -- src/router.jl:121-125 (exact: see netflows_)"""
     ψ = np.zeros_like(r.v)
-    netflows_(ψ, r)
+    netflows_(ψ, r, exact)
     return ψ
 
 

