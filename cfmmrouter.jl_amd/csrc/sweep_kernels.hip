@@ -671,7 +671,10 @@ struct UniV3OpsT {
                     if (adv < 4 || j >= count) break;
                 }
             }
-            j = j < count ? j : count;   // (prices <= 0 from a caller's device vector pass every test, the closing 0 included)
+            // (prices <= 0 from a caller's device vector pass every test, the closing 0 included: the closing record, whose
+            //  threshold is 0 whichever path found it -- ADVICE r5)
+            thr_t = j < count ? thr_t : 0.0;
+            j = j < count ? j : count;
             rec = p.ticks[begin + j];                                      // (j == count: the list's closing record)
             thr_j = thr_t;                                                 // T[j] (or the float just above it) of the tick the scan stopped at
             have = true;
