@@ -69,9 +69,9 @@ import torch
 import torch.distributed as dist
 
 import cfmmrouter_amd as cr
-from benchlib.legs import finish_route, host_boundary_leg, roofline_record, route_leg, single_process_main
+from benchlib.legs import expanded_leg, finish_route, host_boundary_leg, roofline_record, route_leg, single_process_main
 from benchlib.shard import ShardBench, collectives_leg, sharded_route
-from benchlib.traffic import live_traffic
+from benchlib.traffic import live_kernel_stats, live_traffic
 from benchlib.workloads import METRIC, WORKLOADS, build_global, objective_for   # noqa: F401  (scripts import WORKLOADS from here)
 
 
@@ -255,7 +255,8 @@ def other_configs(args, local_rank, budget_s):
                    "kernel_ms_warm": warm_ms, "kernel_ms_hbm_resident": cold["kernel_ms"], "reduce_kernel_ms": kt["reduce_ms"] / sub.steps,
                    "alg_bytes_per_launch": ab, "frac": cold["frac"], "frac_warm": ab / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "traffic": tr, "bus_frac": (tr / (cold["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
-                   "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes of this workload)" if tr else None,
+                   "traffic_is": "committed" if tr else None,
+                   "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes of this workload, NOT measured in this run)" if tr else None,
                    "step_frac": ab / (1e3 * elapsed / sub.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "ring": {k: cold[k] for k in ("copies", "touched_per_copy", "bytes_touched", "hbm_resident")}}
             # parity at fixed v: the timed path's {Ψ, acc} against ONE sweep of the CPU restatement
@@ -288,6 +289,63 @@ def other_configs(args, local_rank, budget_s):
             out[name] = rec
         except Exception as e:      # informational block: never lose the bench line over it
             out[name] = {"error": repr(e)[:300]}
+    # BASELINE config 4 AT ITS STATED SIZE on this one GPU: 4M ProductTwoCoin pools, 512 tokens, 8 shards of
+    # 500k pools through ONE multi-device context with the device listed 8 times (cfmm_ctx_create_multi: 8 pool stores, 8 streams,
+    # 8 host worker threads; the shards' {Ψ, acc} summed on the host) -- what an 8-GPU node executes, minus the placement.
+    # A step here is a host-pointer cfmm_find_arb (PCIe-inclusive: the multi-device context has no device-pointer sweep).
+    if time.perf_counter() - t_start > budget_s:
+        out.setdefault("skipped", []).append("config4_full")
+        return out
+    t0 = time.perf_counter()
+    try:
+        from benchlib.workloads import build_market, sweep_prices_for
+        n = WORKLOADS["config4"][1]
+        batches = build_market("config4", 0, 1, "weak")
+        m = sum(len(b) for b in batches)
+        v = sweep_prices_for("config4", n)
+        be = cr.DeviceBackend(n, batches, device=[local_rank] * 8)
+        try:
+            for _ in range(3):
+                be.ctx.find_arb(v)
+            ts = []
+            for _ in range(10):
+                t1 = time.perf_counter()
+                be.ctx.find_arb(v)
+                ts.append(time.perf_counter() - t1)
+            psi = np.concatenate([be.ctx.netflows(), [be.ctx.dual_value()]])
+            rec = {"workload": WORKLOADS["config4"][0] + "; 8 shards of 500k pools on ONE GPU through one multi-device context",
+                   "pools": m, "n_tokens": n, "shards": 8, "ms_per_step": 1e3 * float(np.median(ts)), "ms_per_step_min": 1e3 * min(ts),
+                   "value": m / float(np.median(ts)),
+                   "value_is": "host-pointer cfmm_find_arb over all 8 shards (v in, Ψ out over PCIe every step; 8 concurrent sweeps "
+                               "share the one GPU): pools / median call time"}
+            ps = oracle_poolset(batches, n)
+            D, L = np.empty((ps.m, 2)), np.empty((ps.m, 2))
+            ps.sweep_into(v, D, L, min(64, HOST_CPUS))
+            G = np.zeros(n)
+            orc.grad_scatter(G, D, L, ps.Ai)
+            acco = orc.dual_acc(D, L, ps.Ai, v)
+            Dd, Ld = be.trades()
+            rec["parity"] = {"netflow_rel_err_at_fixed_v": float(np.max(np.abs(psi[:n] - G)) / np.max(np.abs(G))),
+                             "dual_rel_err": float(abs(psi[n] - acco) / max(abs(acco), 1.0)),
+                             "all_trade_rows_bit_equal": bool(np.array_equal(Dd, D) and np.array_equal(Ld, L))}
+            del D, L, Dd, Ld
+            obj = objective_for("config4", n)
+            r = cr.Router(obj, batches, n, _backend=be)
+            cr.route_(r, v=np.ones(n), solver="native")
+            tr = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                cr.route_(r, v=np.ones(n), solver="native")
+                tr.append(time.perf_counter() - t1)
+            rec["route_ms"] = 1e3 * min(tr)
+            rec["route_evaluations"] = r.info.get("funcalls")
+            rec["parity"].update(fortran_parity("config4", {"_psi_native": cr.netflows(r).copy()}, m))
+        finally:
+            be.close()
+        rec["seconds"] = time.perf_counter() - t0
+        out["config4_full"] = rec
+    except Exception as e:
+        out["config4_full"] = {"error": repr(e)[:300]}
     return out
 
 
@@ -537,6 +595,27 @@ def main():
         "library_options": {k: be.ctx.get_option(k) for k in ("pack", "compact_trades", "alternate", "fast_math", "armed",
                                                                "stop_in_noise", "host_flag", "zero_copy")},
     }
+    if world == 1 and not use_dist and not args.no_cpu and not args.no_live_traffic and not args.cold_only and cold is not None:
+        # the HBM-resident kernel span as rocprofv3 reports it (a --cold-only child of this command under --kernel-trace --stats):
+        # `kernel_ms`, `frac` and `frac_bus` are quoted on THAT clock -- the one profiles/ holds -- with the hipEvent figure beside it
+        ks, why = live_kernel_stats(__file__, args.workload, args.fused, args.opt)
+        roof = line["roofline"]
+        roof["kernel_ms_hip_events"] = roof["kernel_ms"]
+        if ks is not None and ks["avg_ms"] > 0:
+            ab = roof["alg_bytes_per_launch"]
+            roof.update(kernel_ms=ks["avg_ms"], kernel_ms_source="rocprofv3 --kernel-trace --stats of a --cold-only child run of this "
+                        "command: average of %d launches of %s (min %.2f us, max %.2f us)" % (ks["calls"], ks["kernel"], 1e3 * ks["min_ms"], 1e3 * ks["max_ms"]),
+                        achieved=ab / (ks["avg_ms"] * 1e-3) / 1e9, frac=ab / (ks["avg_ms"] * 1e-3) / 1e9 / roof["peak"])
+            if roof.get("traffic"):
+                roof["bus_frac"] = roof["frac_bus"] = roof["traffic"] / (ks["avg_ms"] * 1e-3) / 1e9 / roof["peak"]
+            roof["frac_hip_events"] = ab / (roof["kernel_ms_hip_events"] * 1e-3) / 1e9 / roof["peak"]
+        else:
+            roof["kernel_ms_source"] = "hipEvent pairs written by the command processor around every sweep launch (rocprofv3 child unavailable: %s)" % why
+    if world == 1 and not use_dist and not args.no_cpu and not args.fused and not args.cold_only:
+        try:
+            line["roofline"]["expanded"] = expanded_leg(sb, args, local_rank)
+        except Exception as e:
+            line["roofline"]["expanded"] = {"error": repr(e)[:200]}
     if cold is not None:
         # the HBM-resident step beside `value` (which is the cache-warm step: the same market every step, as inside route!)
         line["value_hbm_resident"] = world * sb.m_rank / (cold["ms_per_step"] * 1e-3)
@@ -645,8 +724,14 @@ def main():
                               "kernel time + frac, bus_frac from the committed PMC bytes, parity at fixed v vs the CPU restatement "
                               "and route! vs the Fortran L-BFGS-B fixture; `config.cfg_*` repeat them as one-line strings")
         for k, rec in line["configs"].items():
-            if isinstance(rec, dict):
+            if isinstance(rec, dict) and k != "config4_full":
                 line["config"]["cfg_" + k] = summary_string(rec)
+        c4 = line["configs"].get("config4_full")
+        if isinstance(c4, dict) and "error" not in c4:
+            line["config"]["cfg_config4_full"] = ("4M pools 8 shards 1 GPU: find_arb %.2fms | rows bit-equal %s fixv %.0e | route! %.2fms %s evals fortran %s" % (
+                c4["ms_per_step"], c4["parity"]["all_trade_rows_bit_equal"], c4["parity"]["netflow_rel_err_at_fixed_v"], c4["route_ms"],
+                c4["route_evaluations"], ("%.0e" % c4["parity"]["route_native_vs_fortran_netflow_rel_err"])
+                if "route_native_vs_fortran_netflow_rel_err" in c4["parity"] else "-"))[:160]
         try:     # the kernel against the roofline where the launch floor no longer matters
             sc = at_scale_leg(args, local_rank)
             line["roofline"]["at_scale"] = sc

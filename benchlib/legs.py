@@ -185,6 +185,71 @@ def host_boundary_leg(sb):
     return host
 
 
+def expanded_leg(sb, args, local_rank):
+    """What the API-faithful materialisation costs.  The timed step writes ONE 16-byte record per pool
+    (lossless; `compact_trades`); the reference's r.Δs / r.Λs are 32 bytes per pool (src/router.jl:7-8,40).  Two ways to have
+    those rows device-resident, both timed here on the same market, outside the timed region:
+      expanded    the timed step followed by cfmm_trades_dev (the `expand_trades` kernel: 16 B read + 32 B written per pool);
+      plain_rows  the sweep itself writing {Δ₁, Δ₂} / {Λ₁, Λ₂} (option compact_trades = 0): the sweep of rounds 1-2.
+    Each as the cache-warm step and (plain_rows) the HBM-resident kernel, with `frac` in the reference's bytes -- which these
+    variants really move."""
+    import argparse
+    from .shard import ShardBench
+    from .workloads import HBM_PEAK_GBS, alg_bytes
+    out = {}
+    K = max(args.steps, 100)
+    be, st = sb.be, sb.stream
+    m = sb.m_rank
+
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fn()
+        while not st.query():
+            pass
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / K
+
+    def sweep_only():
+        be.ctx.sweep_dev(sb.v_t.data_ptr(), sb.out_t.data_ptr(), True)
+
+    def sweep_and_expand():
+        be.ctx.sweep_dev(sb.v_t.data_ptr(), sb.out_t.data_ptr(), True)
+        be.ctx.trades_dev()
+
+    t_plain, t_exp = timed(sweep_only), timed(sweep_and_expand)
+    ab = alg_bytes(sb.batches, True, sb.v)
+    out["expanded"] = {"ms_per_step": t_exp, "ms_per_step_compact_only": t_plain, "expand_ms": t_exp - t_plain,
+                       "expand_bytes": 48 * m, "value": m / (t_exp * 1e-3),
+                       "step_frac": ab / (t_exp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "is": "cache-warm step = sweep + fold + expand_trades (cfmm_trades_dev): the reference-layout rows device-resident "
+                             "after every step; step_frac = reference bytes / that step / 8 TB/s"}
+    sub = argparse.Namespace(**vars(args))
+    sub.opt = list(args.opt) + ["compact_trades=0"]
+    sub.fused = False
+    s2 = ShardBench(sub, sb.name, "weak", 0, 1, local_rank, False)
+    try:
+        for _ in range(10):
+            s2.step()
+        e2, _ = s2.timed_pass(K)
+        kt, _ = s2.kernel_pass(K)
+        cold = s2.cold_pass(max(args.steps, 60))
+        out["plain_rows"] = {"ms_per_step": 1e3 * e2 / K, "value": m * K / e2, "kernel_ms_warm": kt["sweep_ms"] / K,
+                             "kernel_ms_hbm_resident": cold["kernel_ms"], "ms_per_step_hbm_resident": cold["ms_per_step"],
+                             "frac": ab / (cold["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "moved_bytes_per_launch": ab - 8 * m,
+                             "is": "option compact_trades = 0: the sweep writes the reference's 32-byte Δ/Λ rows itself; frac = reference "
+                                   "bytes (what this variant moves, minus the 8 B per pool the packed fee/token record saves) / "
+                                   "HBM-resident kernel time / 8 TB/s"}
+    finally:
+        s2.close()
+        torch.cuda.set_stream(sb.stream)
+    return out
+
+
 def roofline_record(sb, args, ms_per_step, sweep_ms, reduce_ms, elapsed2, cold, traffic, traffic_src, traffic_detail):
     """Roofline of the dominant kernel (the sweep launch).  Headline = pool state resident in HBM (the cold pass, or the whole
     timed region with --cold-only): every working set here fits the 256 MB Infinity Cache, so the warm figure (same market
@@ -227,8 +292,11 @@ def roofline_record(sb, args, ms_per_step, sweep_ms, reduce_ms, elapsed2, cold, 
     if traffic and hbm["kernel_ms"] > 0:
         bus = traffic / (hbm["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
-            "frac_is": "algorithmic (reference-layout) bytes of SURVEY 8d per launch / kernel time / 8 TB/s -- an accounting "
-                       "unit; read `bus_frac` as the fraction of the bus",
+            "frac_bus": bus,
+            "frac_is": "frac = algorithmic (reference-layout) bytes of SURVEY 8d per launch / HBM-resident kernel time / 8 TB/s: the "
+                       "contract's accounting unit -- the timed sweep writes a 16-byte record per pool where the reference's rows are 32 "
+                       "(`expanded` prices what producing those rows costs).  frac_bus (= bus_frac) = the bytes the PMC counters saw "
+                       "the launch move / the same kernel time / 8 TB/s: the fraction of the bus, the figure to judge the kernel by",
             "traffic": traffic, "bus_frac": bus, "traffic_source": traffic_src, "traffic_detail": traffic_detail,
             "kernel": "cfmm::sweep_multi / cfmm::sweep_kernel (the sweep launch of one step)",
             "alg_bytes_per_launch": bytes_per_launch, "kernel_ms": hbm["kernel_ms"], "residency": resid,

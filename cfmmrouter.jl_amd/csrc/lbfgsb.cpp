@@ -318,20 +318,18 @@ struct Memory {
     }
 };
 
+// max_i |proj g_i|.  hl / hu: 1.0 where the variable has a (finite) lower / upper bound, else 0.0 -- selects instead of
+// branches, so the loop vectorises (max is exact: no rounding, any order)
 double projected_gradient_norm(int n, const double* x, const double* g, const double* l, const double* u,
-                               const int* nbd)
+                               const double* hl, const double* hu)
 {
     double nrm = 0.0;
     for (int i = 0; i < n; ++i) {
-        double gi = g[i];
-        if (nbd[i] != 0) {
-            if (gi < 0.0) {
-                if (has_upper(nbd[i])) gi = std::max(x[i] - u[i], gi);
-            } else {
-                if (has_lower(nbd[i])) gi = std::min(x[i] - l[i], gi);
-            }
-        }
-        nrm = std::max(nrm, std::fabs(gi));
+        const double gi = g[i];
+        const double up = hu[i] != 0.0 ? std::max(x[i] - u[i], gi) : gi;   // gi < 0
+        const double lo = hl[i] != 0.0 ? std::min(x[i] - l[i], gi) : gi;   // gi >= 0
+        const double pgi = gi < 0.0 ? up : lo;
+        nrm = std::max(nrm, std::fabs(pgi));
     }
     return nrm;
 }
@@ -344,7 +342,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
     LbfgsbResult res;
     const int m = std::max(1, opt.m);
     std::vector<int> nbd(nbd_in, nbd_in + n);
-    std::vector<double> l(n), u(n);
+    std::vector<double> l(n), u(n), hlm(n), hum(n);   // hlm / hum: 1.0 where the variable has a finite lower / upper bound
     bool constrained = false, boxed = true, boxed_as_given = true;
     for (int i = 0; i < n; ++i) {
         if (nbd_in[i] != 2) boxed_as_given = false;
@@ -354,6 +352,10 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         const bool hl = has_lower(nbd[i]) && std::isfinite(l[i]);
         const bool hu = has_upper(nbd[i]) && std::isfinite(u[i]);
         nbd[i] = hl ? (hu ? 2 : 1) : (hu ? 3 : 0);
+        hlm[i] = hl ? 1.0 : 0.0;
+        hum[i] = hu ? 1.0 : 0.0;
+        if (!hl) l[i] = -kInf;      // (a bound that does not exist never binds: the branch-free loops below rely on it)
+        if (!hu) u[i] = kInf;
         if (nbd[i] != 0) constrained = true;
         if (nbd[i] != 2) boxed = false;
         // project the starting point into the box
@@ -385,7 +387,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         res.f = f;
         return res;
     }
-    double pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+    double pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), hlm.data(), hum.data());
     if (pg <= opt.pgtol) {
         res.f = f;
         res.proj_grad = pg;
@@ -413,22 +415,40 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             order.clear();
             double dtd = 0.0;
             int moving = 0;
-            for (int i = 0; i < n; ++i) {
-                double ti = kInf;
-                if (g[i] < 0.0 && has_upper(nbd[i])) ti = (x[i] - u[i]) / g[i];
-                else if (g[i] > 0.0 && has_lower(nbd[i])) ti = (x[i] - l[i]) / g[i];
-                t[i] = ti;
-                fixed[i] = 0;
-                if (ti <= 0.0) { // at its bound with the gradient pushing outward
-                    d[i] = 0.0;
-                    fixed[i] = 1;
-                } else {
-                    d[i] = -g[i];
-                    dtd += d[i] * d[i];
-                    if (d[i] != 0.0) ++moving;
-                    if (std::isfinite(ti)) order.push_back(i);
+            // breakpoints, branch-free (vectorised): t_i = (x_i − u_i)/g_i for g_i < 0, (x_i − l_i)/g_i for g_i > 0, +inf where
+            // that bound does not exist (l = −inf / u = +inf there: the quotient itself is +inf) or g_i = 0
+            {
+                const double* __restrict gp = g.data();
+                const double* __restrict lp = l.data();
+                const double* __restrict up = u.data();
+                const double* __restrict xp = x;
+                double* __restrict tp = t.data();
+                double* __restrict cp = xcp.data();
+                for (int i = 0; i < n; ++i) {
+                    const double gi = gp[i], xi = xp[i];
+                    const double num = gi < 0.0 ? xi - up[i] : xi - lp[i];
+                    const double ti = num / gi;                       // g = 0: ±inf or NaN, replaced below
+                    tp[i] = gi != 0.0 ? ti : kInf;
+                    cp[i] = xi;
                 }
-                xcp[i] = x[i];
+                // ... then the (order-dependent) bookkeeping: the sum d'd in index order, the heap's candidates
+                double* __restrict dp = d.data();
+                int* __restrict fp_ = fixed.data();
+                order.resize(n);
+                int* __restrict op = order.data();
+                int cand = 0;
+                for (int i = 0; i < n; ++i) {
+                    const double ti = tp[i];
+                    const bool fx = ti <= 0.0;                        // at its bound with the gradient pushing outward
+                    const double di = fx ? 0.0 : -gp[i];
+                    fp_[i] = fx ? 1 : 0;
+                    dp[i] = di;
+                    dtd += di * di;
+                    moving += di != 0.0 ? 1 : 0;
+                    op[cand] = i;
+                    cand += (!fx && ti < kInf) ? 1 : 0;
+                }
+                order.resize(cand);
             }
             // breakpoints are consumed in increasing order, usually only the first few: a min-heap
             // (the Fortran's hpsolb) instead of a full sort
@@ -693,7 +713,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         ++iter;
 
         // ---------------- termination tests ------------------------------------------------------
-        pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+        pg = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), hlm.data(), hum.data());
         if (pg <= opt.pgtol) {
             res.status = 0;
             res.message = "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL";
@@ -730,7 +750,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
 
     res.f = f;
     res.iterations = iter;
-    res.proj_grad = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), nbd.data());
+    res.proj_grad = projected_gradient_norm(n, x, g.data(), l.data(), u.data(), hlm.data(), hum.data());
     return res;
 }
 

@@ -105,7 +105,15 @@ def test_bench_default_line_and_reference_grid():
     assert roof["bound"] == "hbm" and 0.2 < roof["frac"] < 1.0 and roof["cold"]["ms_per_step"] > 0
     assert roof["cold"]["ms_per_step"] <= roof["cold"]["ms_per_step_with_kernel_events"]
     if roof["traffic"]:
-        assert 0.1 < roof["bus_frac"] < 1.0
+        assert 0.1 < roof["bus_frac"] < 1.0 and roof["frac_bus"] == roof["bus_frac"]
+    # round 6: the kernel span on rocprofv3's clock (what profiles/ holds) with the hipEvent figure beside it (within 10 %),
+    # and what producing the reference's 32-byte rows costs (expand kernel / plain-rows sweep)
+    assert "kernel_ms_source" in roof and abs(roof["kernel_ms"] - roof["kernel_ms_hip_events"]) <= 0.1 * roof["kernel_ms"]
+    ex = roof["expanded"]
+    assert ex["expanded"]["ms_per_step"] >= ex["expanded"]["ms_per_step_compact_only"] and 0 < ex["plain_rows"]["frac"] < 1.0
+    c4 = line["configs"]["config4_full"]
+    assert c4["pools"] == 4_000_000 and c4["shards"] == 8 and c4["parity"]["all_trade_rows_bit_equal"]
+    assert c4["parity"]["netflow_rel_err_at_fixed_v"] <= 1e-12 and c4["parity"]["route_native_vs_fortran_netflow_rel_err"] <= 1e-6
     assert par["netflow_rel_err_at_fixed_v"] <= 1e-12 and par["route_native_netflow_rel_err"] <= 1e-6
     assert par["route_converged_netflow_rel_err"] <= 1e-8
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
