@@ -216,7 +216,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
         {"fast_math", &c->opt_fast_math}, {"armed", &c->opt_armed}, {"arm_timeout_ms", &c->opt_arm_timeout_ms},
         {"cost_geomean", &c->opt_cost_geomean}, {"cost_univ3", &c->opt_cost_univ3}, {"host_flag", &c->opt_host_flag},
         {"stop_in_noise", &c->opt_stop_in_noise}, {"multi_threads", &c->opt_multi_threads},
-        {"dev_prices_in_window", &c->opt_dev_prices_in_window}, {"univ3_heads", &c->opt_univ3_heads},
+        {"dev_prices_in_window", &c->opt_dev_prices_in_window}, {"univ3_heads", &c->opt_univ3_heads}, {"direct_small", &c->opt_direct_small},
 #ifdef CFMM_TEST_HOOKS
         {"debug_stall_ms", &c->opt_debug_stall_ms},
 #endif
@@ -244,7 +244,7 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
         }
     if (slot == &c->opt_max_grid || slot == &c->opt_block || slot == &c->opt_fuse_segments ||
         slot == &c->opt_geomean_exact || slot == &c->opt_pack ||
-        slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3)
+        slot == &c->opt_cost_geomean || slot == &c->opt_cost_univ3 || slot == &c->opt_direct_small)
         c->geometry_dirty = true;
     return CFMM_OK;
 }

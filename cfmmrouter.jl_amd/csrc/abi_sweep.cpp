@@ -38,6 +38,13 @@ int fused_grid_cap(const cfmm_ctx* c, int block)
 // (and the fold kernel) small.  Large-market mode (global bins) uses 512-thread blocks throughout.
 void plan_segment(const cfmm_ctx* c, Segment& s)
 {
+    // tiny single-family markets: ONE block, whose row is the result (SweepArgs::direct: no fold launch)
+    if (c->opt_direct_small != 0 && c->segs.size() == 1 && s.m <= kDirectPools && !global_bins(c) && c->opt_block == 0 &&
+        c->opt_max_grid == 0) {
+        s.block = kBigBlock;
+        s.grid = 1;
+        return;
+    }
     const int64_t tiles_mid = std::max<int64_t>(1, (s.m + kMidBlock - 1) / kMidBlock);
     const bool small = global_bins(c) || c->opt_block == kMidBlock || (c->opt_block == 0 && tiles_mid <= 256);
     if (small) {
@@ -325,6 +332,9 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         ho.tag = c->out_seq % 0xffffffffull + 1ull;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    // a launch of one block needs no fold: its row goes straight to the consumer (single-GPU contexts: a sharded fold also
+    // exchanges, and RCCL all-reduces d_out behind the fold)
+    const bool direct = c->groups.size() == 1 && c->groups[0].grid == 1 && !c->groups[0].multi && !gb && !sharded;
     size_t group_index = 0;
     for (const Group& g : c->groups) {
         const size_t gi = group_index++;
@@ -355,6 +365,11 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         // equally long turns a stalled host into a slow evaluation on every rank instead of a failed route on all of them
         if (sharded) a.arm_timeout = std::max<long long>(a.arm_timeout, c->peer_timeout_ticks);
         a.flags = c->d_stage ? reinterpret_cast<unsigned long long*>(c->d_stage + c->flag_off) : nullptr;
+        if (direct) {
+            a.direct = 1;
+            a.direct_out = d_out;
+            a.direct_host = ho;
+        }
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double)
                               : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n, a.v_shift == 4 ? 1 : 0);
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -431,13 +446,15 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
     c->last_host_out = host_out;
     hipEvent_t ra = nullptr, rb = nullptr;
     const bool bracket = gb || (c->rows_total == 0 && !sharded);   // several launches / a memset: bracket them with plain events
-    if (timed) {
+    if (timed && !direct) {
         ra = take_event(c);
         rb = take_event(c);
         if (!ra || !rb) ra = rb = nullptr;
         if (ra && bracket) HIP_TRY(c, hipEventRecord(ra, c->stream));
     }
-    if (sharded) {
+    if (direct) {
+        // (the sweep's only block has published {Ψ, acc} itself)
+    } else if (sharded) {
         PeerSet ps;
         std::memset(&ps, 0, sizeof ps);
         const int64_t count = c->n + 1;

@@ -198,6 +198,8 @@ struct cfmm_ctx {
     int64_t opt_stop_in_noise = 0; // cfmm_route: 1 = end the run when a line-search trial point sits on the rounding-noise floor
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
+    int64_t opt_direct_small = 1;  // 1: single-family markets of up to kDirectPools pools are swept by ONE block that publishes {Ψ, acc}
+                                   //    itself (no fold launch); 0: the general two-launch geometry
     int64_t opt_univ3_heads = 1;   // 1: multi-tick UniV3 walks decide their first four list ticks from the per-pool float threshold heads
     int64_t opt_dev_prices_in_window = 0; // 1 = the CALLER vouches that the prices of device-pointer sweeps lie in [2^-kFastExp, 2^kFastExp]
                                      //    (what the host checks itself for host-pointer calls): cfmm_sweep_dev launches the fast kernels

@@ -91,6 +91,14 @@ struct UniV3Pools {              // src/cfmms.jl:226-245 as find_arb_pos constan
     int gbase;
 };
 
+// How a fold launch hands {Ψ, acc} to the host (mapped pinned memory), if at all: gran != null -> the block's 8 columns
+// leave as 16 SELF-VALIDATING 8-byte granules {tag, 32 bits of the double} (two per column) written by one store
+// instruction = two full 64-byte lines; the host re-reads them until all carry the tag -- no drain of the output stores,
+// no ticket, no flag word.  gran == null: plain stores to `out` (device consumers).
+struct HostOut {
+    unsigned long long* gran;    // [2 * ceil8(n1)] words in mapped host memory, or null
+    unsigned long long tag;      // 1 .. 2^32 - 1 (0 = an empty buffer)
+};
 struct SweepArgs {
     const double* v;             // [n] device
     int n;                       // n_tokens
@@ -131,7 +139,15 @@ struct SweepArgs {
     const unsigned long long* arm_word;
     unsigned long long arm_seq;
     long long arm_timeout;
+    // Single-block launches (grid == 1: markets of up to kDirectPools pools, one family): the block's row IS the result, so
+    // it goes straight to `direct_out` (device consumers) or -- direct_host.gran set -- to the host as granules, and NO fold
+    // launch follows: one kernel per evaluation instead of two (the reference's own benchmark grid, benchmark/scaling.jl:8-38,
+    // is all markets of this size, where an evaluation is launch latency and nothing else).
+    int direct;
+    double* direct_out;          // [n + 1] {Ψ, acc}
+    HostOut direct_host;
 };
+constexpr int kDirectPools = 2048;   // two tiles of a 1024-thread block
 constexpr unsigned long long kArmCancel = 1ull << 63;
 constexpr unsigned long long kFlagWindow = 1;   // a fast kernel staged a price outside [2^-kFastExp, 2^kFastExp]: rows poisoned
 constexpr unsigned long long kFlagGaveUp = 2;   // a pre-armed launch gave up waiting for its price vector: rows poisoned
@@ -194,14 +210,6 @@ hipError_t launch_multi(const MultiArgs& ma, const LaunchCfg& c, bool materializ
 hipError_t launch_gather(const int2* chunks, const int* entries, const double* flow, double* chunk_sums, int n_chunks,
                          const int* tok_chunk_off, double* out, int n, const double* acc_rows, int rows, hipStream_t s);
 
-// How a fold launch hands {Ψ, acc} to the host (mapped pinned memory), if at all: gran != null -> the block's 8 columns
-// leave as 16 SELF-VALIDATING 8-byte granules {tag, 32 bits of the double} (two per column) written by one store
-// instruction = two full 64-byte lines; the host re-reads them until all carry the tag -- no drain of the output stores,
-// no ticket, no flag word.  gran == null: plain stores to `out` (device consumers).
-struct HostOut {
-    unsigned long long* gran;    // [2 * ceil8(n1)] words in mapped host memory, or null
-    unsigned long long tag;      // 1 .. 2^32 - 1 (0 = an empty buffer)
-};
 struct ArmWord {                 // see SweepArgs::arm_word; {nullptr, 0} = not armed
     const unsigned long long* word;
     unsigned long long seq;

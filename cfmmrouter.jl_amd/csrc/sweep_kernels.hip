@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void tile_loop(const Ops& ops, const SweepArgs& a, co
 constexpr int kArithFull = 0, kArithFast = 1, kArithAuto = 2;
 template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK, bool MULTI>
 __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a, const SweepLds& L, int bid, int nblocks,
-                                              bool& poison)
+                                              bool& poison, bool& live)
 {
     static_assert(!(GBINS && FASTK != kArithFull), "large-market mode runs on the compiler's sequences");
     double acc = 0.0;
@@ -1039,6 +1039,7 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
     if (left > 0) cur = ops.template load<GBINS>(i);
     const int staged = stage_prices<BLOCK, GBINS>(a, L);
     poison = (staged & kStageLive) == 0;              // a pre-armed launch that is not needed (or gave up)
+    live = !poison || (staged & kStageGaveUp) != 0;   // false: CANCELLED by the host (a launch that gave up waiting still reports NaN)
     if (staged & kStageGaveUp) report(a, kFlagGaveUp);
     if (FASTK == kArithFast && !poison && (staged & kStageFast) == 0) {
         poison = true;                                // prices outside the window of this kernel's arithmetic
@@ -1059,8 +1060,23 @@ __device__ __forceinline__ double sweep_tiles(const Ops& ops, const SweepArgs& a
 
 // Block epilogue: fold the dual scalar (lanes by wave shuffles, waves through LDS, fixed order), fold
 // the bin copies in a fixed order and write the block's partial row.
+// Column j of a single-block launch's result, straight to its consumer (SweepArgs::direct): a plain store for device
+// consumers, or the column's two self-validating granules {tag, 32 bits} as ONE 16-byte system-scope store -- adjacent lanes
+// write adjacent columns, so a wavefront's store covers full 64-byte lines on the PCIe side (see fold_finish).
+typedef unsigned long long u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void publish_column(const SweepArgs& a, int j, double val)
+{
+    if (a.direct_host.gran) {
+        const unsigned long long tag = (a.direct_host.tag & 0xffffffffull) << 32, u = (unsigned long long)__double_as_longlong(val);
+        u2v g = {tag | (u & 0xffffffffull), tag | (u >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(a.direct_host.gran + 2 * (size_t)j), "v"(g) : "memory");
+    } else {
+        a.direct_out[j] = val;
+    }
+}
+
 template <int BLOCK, bool GBINS>
-__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id, bool poison)
+__device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L, double acc, int row_id, bool poison, bool publish)
 {
     const double nan = __builtin_nan("");
     if (poison) acc = nan;                               // every column of a poisoned row is NaN: whoever folds it sees an error
@@ -1073,6 +1089,22 @@ __device__ __forceinline__ void finish_row(const SweepArgs& a, const SweepLds& L
     __syncthreads();
 
     const int n_cols = GBINS ? 0 : a.n;                  // Ψ columns of the partial row
+    if (!GBINS && a.direct) {
+        // the only block of its launch: the row is the result.  A cancelled pre-armed launch publishes nothing (the fold of
+        // such an evaluation returns without output as well: the host has moved on and may reuse the sequence tag)
+        if (!publish) return;
+        for (int j = tid; j < n_cols; j += BLOCK) {
+            double s = L.bins[j];
+            for (int c = 1; c < a.copies; ++c) s += L.bins[(size_t)c * a.n_pad + j];
+            publish_column(a, j, poison ? nan : s);
+        }
+        if (tid == 0) {
+            double s = L.wsum[0];
+            for (int w = 1; w < kWaves; ++w) s += L.wsum[w];
+            publish_column(a, n_cols, poison ? nan : s);
+        }
+        return;
+    }
     double* row = a.partials + (size_t)row_id * a.row_pitch;   // 128-byte aligned rows (SweepArgs::row_pitch)
     for (int j = tid; j < n_cols; j += BLOCK) {
         double s = L.bins[j];
@@ -1092,9 +1124,9 @@ template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK, bool MULTI>
 __device__ __forceinline__ void sweep_body(const Ops& ops, const SweepArgs& a, int bid, int nblocks, int row_id)
 {
     const SweepLds L = carve_lds<BLOCK, GBINS>(a);
-    bool poison;
-    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS, FASTK, MULTI>(ops, a, L, bid, nblocks, poison);
-    finish_row<BLOCK, GBINS>(a, L, acc, row_id, poison);
+    bool poison, live;
+    const double acc = sweep_tiles<Ops, MAT, BLOCK, GBINS, FASTK, MULTI>(ops, a, L, bid, nblocks, poison, live);
+    finish_row<BLOCK, GBINS>(a, L, acc, row_id, poison, live);
 }
 
 template <class Ops, bool MAT, int BLOCK, bool GBINS, int FASTK>

@@ -405,3 +405,102 @@ def test_device_pointer_sweep_with_invalid_prices_stays_in_bounds(bad):
     finally:
         be.close()
 
+
+
+# ---- single-block launches: the block publishes {Ψ, acc} itself, no fold launch (SweepArgs::direct, round 6) -------------------
+
+def _small_market(kind, m, n, seed):
+    if kind == "product":
+        return synth.product_pools(m, n, seed=seed)
+    if kind == "geomean":
+        return synth.geomean_pools(m, n, seed=seed)
+    if kind == "bounded":
+        return synth.bounded_product_pools(m, n, seed=seed)
+    return synth.univ3_pools(m, n, 6, seed=seed)
+
+
+@pytest.mark.parametrize("kind", ["product", "geomean", "bounded", "univ3"])
+@pytest.mark.parametrize("m", [1, 100, 1500, 2048, 2049])
+def test_single_block_markets_publish_their_result_without_a_fold(kind, m):
+    """Markets of up to 2048 pools of one family (the reference's own benchmark grid, benchmark/scaling.jl:8-38, is all this
+    size) are swept by ONE 1024-thread block whose row IS the result: it goes straight to the host granules / the device
+    output, and no fold launch follows (option direct_small, default on; 2049 pools: the general two-launch geometry).
+    Same trades bit for bit as the two-launch form and as the CPU restatement; Ψ to summation-order rounding; host-pointer
+    and device-pointer sweeps, fused and materialising, 50 price vectors back to back."""
+    import torch
+    n = 24
+    b = _small_market(kind, m, n, 900 + m)
+    one, two = cr.DeviceBackend(n, [b]), cr.DeviceBackend(n, [b])
+    two.ctx.set_option("direct_small", 0)
+    try:
+        seg1, seg2 = one.ctx.segments()[0], two.ctx.segments()[0]
+        assert (seg1["grid"] == 1 and seg1["block"] == 1024) == (m <= 2048)
+        assert seg2["block"] == 512 and seg2["grid"] == (m + 511) // 512
+        vt = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ot = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        for it in range(50):
+            v = synth.sweep_prices(n, seed=70 + it, spread=0.4)
+            Do, Lo, psi_o, acc_o = oracle_sweep([b], n, v)
+            scale = max(np.max(np.abs(psi_o)), 1e-300)
+            p1, a1 = one.find_arb(v)                                    # host pointer, materialising: granules from the sweep block
+            p2, a2 = two.find_arb(v)
+            D1, L1 = one.trades()
+            D2, L2 = two.trades()
+            np.testing.assert_array_equal(D1, D2)
+            np.testing.assert_array_equal(L1, L2)
+            if kind != "geomean":
+                np.testing.assert_array_equal(D1, Do)
+                np.testing.assert_array_equal(L1, Lo)
+            assert np.max(np.abs(p1 - p2)) <= 1e-13 * scale and np.max(np.abs(p1 - psi_o)) <= 1e-12 * scale
+            assert abs(a1 - a2) <= 1e-13 * max(abs(acc_o), 1.0)
+            pe, ae = one.eval(v)                                        # fused evaluation: same bits as the materialising sweep
+            np.testing.assert_array_equal(pe, p1)
+            assert ae == a1
+            vt.copy_(torch.from_numpy(v))
+            one.ctx.sweep_dev(vt.data_ptr(), ot.data_ptr(), it % 2 == 0)     # device pointer: plain stores to d_out
+            torch.cuda.synchronize()
+            od = ot.cpu().numpy()
+            assert np.max(np.abs(od[:n] - psi_o)) <= 1e-12 * scale
+        if m <= 2048:
+            one.ctx.set_option("time_kernels", 1)
+            one.ctx.kernel_times()
+            one.eval(v)
+            kt = one.ctx.kernel_times()
+            assert kt["sweep_launches"] == 1 and kt["reduce_launches"] == 0      # ONE kernel per evaluation
+    finally:
+        one.close()
+        two.close()
+
+
+def test_route_on_single_block_markets_armed_and_unarmed():
+    """cfmm_route on a 1 000-pool market (one launch per evaluation): pre-armed and launch-when-ready agree bit for bit, a
+    cancelled pre-armed launch (prices outside the fast window) publishes nothing and costs nothing, and the result is the CPU
+    restatement's within north_star's 1e-6."""
+    from cfmmrouter_amd._lib import OBJ_LINEAR_NONNEGATIVE
+    from helpers import oracle_objective, oracle_poolset
+    from oracle import cfmm_oracle as orc
+    n, m = 32, 1000
+    b = synth.product_pools(m, n, seed=1234)
+    c = synth.linear_prices(n, seed=1234)
+    res = []
+    for armed in (1, 0):
+        be = cr.DeviceBackend(n, [b])
+        be.ctx.set_option("armed", armed)
+        try:
+            assert be.ctx.segments()[0]["grid"] == 1
+            for _ in range(3):
+                v, psi, info = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=np.ones(n))
+            res.append((v, psi, info["evaluations"]) + be.trades())
+            # prices far outside [2^-150, 2^150]: the waiting fast-kernel launch is cancelled, the evaluation repeats full-range
+            c_far = c * 2.0 ** 170
+            v2, psi2, info2 = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c_far, 0, v0=c_far * 1.5)
+            assert np.all(np.isfinite(psi2)) and info2["evaluations"] >= 1
+            v3, psi3, _ = be.ctx.route(OBJ_LINEAR_NONNEGATIVE, c, 0, v0=np.ones(n))      # clean state afterwards
+            np.testing.assert_array_equal(v3, v)
+            np.testing.assert_array_equal(psi3, psi)
+        finally:
+            be.close()
+    for x, y in zip(res[0], res[1]):
+        np.testing.assert_array_equal(x, y)
+    ref = orc.route_oracle(oracle_objective(cr.LinearNonnegative(c)), oracle_poolset([b], n), v0=np.ones(n))
+    assert rel_to_max(res[0][1], ref["psi"]) <= 1e-6
