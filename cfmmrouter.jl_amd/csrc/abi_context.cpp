@@ -31,7 +31,7 @@ int fail(const cfmm_ctx* c, int code, const char* fmt, ...)
 
 extern "C" {
 
-const char* cfmm_version(void) { return "cfmm_amd 0.5.0 (gfx950)"; }
+const char* cfmm_version(void) { return "cfmm_amd 0.6.0 (gfx950)"; }
 
 const char* cfmm_last_error(const cfmm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

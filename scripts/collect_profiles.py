@@ -8,7 +8,7 @@ import sys
 
 import subprocess
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -45,7 +45,8 @@ if os.path.exists(os.path.join(src, "traffic.json")):
 for name in ("floor.txt", "dist_world1.json", "bench_torchrun_world1_peer.json", "bench_torchrun_world1_rccl.json",
              "bench_single_process_3shards.json", "bench_rehearsal_world2.json", "pytest_gpu.log", "smoke.log",
              "route_convergence.txt", "route_kernel_gaps.txt", "ab_options.txt", "ipc_ranks_world2.json", "ipc_ranks_world4.json",
-             "fold_trace.txt", "cpu_baseline_probe.txt", "route_fortran_pin.txt", "kernel_resources.txt"):
+             "fold_trace.txt", "cpu_baseline_probe.txt", "route_fortran_pin.txt", "kernel_resources.txt",
+             "ipc_ranks_config4_world8.json", "bench_scaling_grid.json", "solver_bench.txt"):
     if os.path.exists(os.path.join(src, name)):
         out = {"floor.txt": "launch_floor.txt"}.get(name, name)
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{out}"))

@@ -7,7 +7,8 @@
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 if [ -n "$TESTS" ]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 < /dev/null; tail -4 gpurun_out/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 < /dev/null | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path\|amdgpu.ids" > gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log
+  g++ -O2 -std=c++17 -I include -o /tmp/solver_bench.bin scripts/native/solver_bench.cpp -L cfmmrouter.jl_amd -lcfmm_amd -Wl,-rpath,$R/cfmmrouter.jl_amd -Wl,-rpath,/opt/rocm/lib && { for n in 64 256 512; do /tmp/solver_bench.bin $n 20000 40; done; } > gpurun_out/solver_bench.txt 2>&1; cat gpurun_out/solver_bench.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 < /dev/null; tail -1 gpurun_out/smoke.log
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "parity_by_convergence" 2>&1 < /dev/null | grep -E "default|passed|failed" > gpurun_out/route_convergence.txt; cat gpurun_out/route_convergence.txt
   timeout 900 python -m pytest tests/test_route_fortran_pin.py -m gpu -q -s 2>&1 < /dev/null | grep -E "Fortran|passed|failed" > gpurun_out/route_fortran_pin.txt; cat gpurun_out/route_fortran_pin.txt
