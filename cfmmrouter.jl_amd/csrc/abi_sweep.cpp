@@ -369,6 +369,8 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
             a.direct = 1;
             a.direct_out = d_out;
             a.direct_host = ho;
+            a.reverse = 0;   // two tiles at most, the whole market in one CU's L1: nothing for the alternation to reuse -- and every
+                             // evaluation of such a market, fused or materialising, then returns the same bits at the same prices
         }
         const size_t lds = gb ? (size_t)(g.block / 64) * sizeof(double)
                               : sweep_lds_bytes(c->n_pad, a.copies, g.block, a.need_logv, a.gtab_n, a.v_shift == 4 ? 1 : 0);
