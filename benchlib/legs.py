@@ -303,7 +303,7 @@ def roofline_record(sb, args, ms_per_step, sweep_ms, reduce_ms, elapsed2, cold, 
             "layout": layout, "warm": warm, "cold": cold,
             "step_frac": bytes_per_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "reduce_kernel_ms": reduce_ms, "ms_per_step_with_kernel_events": 1e3 * elapsed2 / args.steps,
-            "how": "kernel_ms = mean duration of the sweep launches (slowest rank), from hipEvent pairs written by the "
-                   "command processor at each kernel's start and stop (hipExtLaunchKernel) on the launch stream; the rocprofv3 "
-                   "averages of the same commands are profiles/r05_*_kernel_stats.csv (warm: --no-cold runs; hbm-resident: "
-                   "--cold-only runs) -- DESIGN.md quotes those and gives this clock in parentheses"}
+            "how": "kernel_ms = mean span of the sweep launches (slowest rank) from hipEvent pairs written by the command processor at "
+                   "each kernel's start and stop (hipExtLaunchKernel) on the launch stream; the default N = 1 run then REPLACES it by "
+                   "the rocprofv3 --kernel-trace --stats average of a --cold-only child of the same command (`kernel_ms_source`; the "
+                   "hipEvent figure stays as `kernel_ms_hip_events`) -- the clock of profiles/r06_*_cold_kernel_stats.csv"}

@@ -216,7 +216,7 @@ def test_stop_in_noise_is_an_option_and_off_by_default():
         be.close()
 
 
-# ---- fault injection, one test per transition of the hand-over protocols that one GPU can reach ----------
+# ---- fault injection, one test per transition of the hand-over protocols that one GPU can reach (protocol table) ----------
 
 def test_prices_outside_the_fast_window_cancel_the_waiting_launch():
     """Transition "armed launch waiting -> prices turn out to be outside [2^-150, 2^150]": the waiting launch runs the fast
