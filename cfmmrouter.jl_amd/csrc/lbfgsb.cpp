@@ -183,6 +183,22 @@ inline double dotn(const double* a, const double* b, int n)
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
+// four dot products against one vector in ONE pass (the masked Gram matrix of the subspace step: the masked column is
+// loaded once for four partners)
+inline void dot4n(const double* __restrict a, const double* __restrict b0, const double* __restrict b1,
+                  const double* __restrict b2, const double* __restrict b3, int n, double out[4])
+{
+#pragma clang fp reassociate(on)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double ai = a[i];
+        s0 += ai * b0[i];
+        s1 += ai * b1[i];
+        s2 += ai * b2[i];
+        s3 += ai * b3[i];
+    }
+    out[0] = s0; out[1] = s1; out[2] = s2; out[3] = s3;
+}
 inline void axpyn(double alpha, const double* x, double* y, int n)
 {
     for (int i = 0; i < n; ++i) y[i] += alpha * x[i];
@@ -437,23 +453,24 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 order.resize(n);
                 int* __restrict op = order.data();
                 int cand = 0;
-                for (int i = 0; i < n; ++i) {
+                for (int i = 0; i < n; ++i) {                         // (vectorised: selects only)
                     const double ti = tp[i];
                     const bool fx = ti <= 0.0;                        // at its bound with the gradient pushing outward
                     const double di = fx ? 0.0 : -gp[i];
                     fp_[i] = fx ? 1 : 0;
                     dp[i] = di;
-                    dtd += di * di;
                     moving += di != 0.0 ? 1 : 0;
+                }
+                dtd = dotn(dp, dp, n);
+                for (int i = 0; i < n; ++i) {                         // the heap's candidates, in index order
                     op[cand] = i;
-                    cand += (!fx && ti < kInf) ? 1 : 0;
+                    cand += (tp[i] > 0.0 && tp[i] < kInf) ? 1 : 0;
                 }
                 order.resize(cand);
             }
             // breakpoints are consumed in increasing order, usually only the first few: a min-heap
             // (the Fortran's hpsolb) instead of a full sort
             auto later = [&](int a, int b) { return t[a] > t[b] || (t[a] == t[b] && a > b); };
-            std::make_heap(order.begin(), order.end(), later);
             mem.Wt_times(d.data(), p.data());   // p = W'd  (d is zero on the variables that do not move)
             double fp = -dtd;
             double fpp = -theta * fp;
@@ -464,6 +481,14 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             const double fpp_org = fpp;
             double dt_min = fpp > 0.0 ? -fp / fpp : 0.0;
             double t_old = 0.0;
+            // The loop below stops at the first breakpoint beyond the minimiser of the first segment: when even the EARLIEST
+            // breakpoint lies beyond it (the usual case once the active set has settled) no heap is needed at all
+            {
+                double t_first = kInf;
+                for (int q : order) t_first = std::min(t_first, t[q]);
+                if (dt_min < t_first) order.clear();
+                else std::make_heap(order.begin(), order.end(), later);
+            }
             size_t heap_end = order.size();
             bool all_fixed = moving == 0;
             while (!all_fixed && heap_end > 0) {
@@ -558,9 +583,19 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                     const double* wa = a < col ? mem.Ycol(a) : mem.Scol(a - col);
                     const double sa = a < col ? 1.0 : theta;
                     for (int i = 0; i < n; ++i) masked[i] = fixed[i] ? 0.0 : sa * wa[i];
-                    for (int b = a; b < k2; ++b) {
-                        const double* wbcol = b < col ? mem.Ycol(b) : mem.Scol(b - col);
-                        const double g_ab = (b < col ? 1.0 : theta) * dotn(masked.data(), wbcol, n);
+                    auto colptr = [&](int b) { return b < col ? mem.Ycol(b) : mem.Scol(b - col); };
+                    int b = a;
+                    for (; b + 3 < k2; b += 4) {          // four partners per pass over the masked column
+                        double g4[4];
+                        dot4n(masked.data(), colptr(b), colptr(b + 1), colptr(b + 2), colptr(b + 3), n, g4);
+                        for (int q = 0; q < 4; ++q) {
+                            const double g_ab = (b + q < col ? 1.0 : theta) * g4[q];
+                            WZ[a * k2 + b + q] = g_ab;
+                            WZ[(b + q) * k2 + a] = g_ab;
+                        }
+                    }
+                    for (; b < k2; ++b) {
+                        const double g_ab = (b < col ? 1.0 : theta) * dotn(masked.data(), colptr(b), n);
                         WZ[a * k2 + b] = g_ab;
                         WZ[b * k2 + a] = g_ab;
                     }
@@ -581,21 +616,27 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 du.resize(nf);
                 wvfull.assign(n, 0.0);
                 mem.W_times_add(v.data(), wvfull.data());             // W v
+                // MN11: project the subspace minimizer onto the box; keep it if it is a descent
+                // direction for the objective, otherwise truncate the step (v2.1 behaviour).
+                // (full-length passes with selects instead of gathers over the free set: they vectorise; l = −inf / u = +inf
+                //  where a bound does not exist, so the clamps are no-ops there; t is scratch for (z − x)·g)
+                {
+                    const double th2 = theta * theta;
+                    const int* __restrict fxp = fixed.data();
+                    double* __restrict zp = z.data();
+                    double* __restrict tp = t.data();
+                    for (int i = 0; i < n; ++i) {
+                        const double dui = -rfull[i] / theta - wvfull[i] / th2;
+                        const double zi = std::min(std::max(xcp[i] + dui, l[i]), u[i]);
+                        zp[i] = fxp[i] ? xcp[i] : zi;
+                        tp[i] = zp[i] - x[i];
+                    }
+                }
                 for (int a = 0; a < nf; ++a) {
                     const int i = free_idx[a];
                     du[a] = -rfull[i] / theta - wvfull[i] / (theta * theta);
                 }
-                // MN11: project the subspace minimizer onto the box; keep it if it is a descent
-                // direction for the objective, otherwise truncate the step (v2.1 behaviour).
-                double dd_p = 0.0;
-                for (int a = 0; a < nf; ++a) {
-                    const int i = free_idx[a];
-                    double xi = xcp[i] + du[a];
-                    if (has_lower(nbd[i])) xi = std::max(xi, l[i]);
-                    if (has_upper(nbd[i])) xi = std::min(xi, u[i]);
-                    z[i] = xi;
-                }
-                for (int i = 0; i < n; ++i) dd_p += (z[i] - x[i]) * g[i];
+                const double dd_p = dotn(t.data(), g.data(), n);
                 if (dd_p > 0.0) {
                     double alpha = 1.0;
                     for (int a = 0; a < nf; ++a) {
@@ -618,12 +659,8 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         }
 
         // ---------------- line search along d = z − x -------------------------------------------
-        double dnorm2 = 0.0, gd = 0.0;
-        for (int i = 0; i < n; ++i) {
-            d[i] = z[i] - x[i];
-            dnorm2 += d[i] * d[i];
-            gd += g[i] * d[i];
-        }
+        for (int i = 0; i < n; ++i) d[i] = z[i] - x[i];
+        const double dnorm2 = dotn(d.data(), d.data(), n), gd = dotn(g.data(), d.data(), n);
         bool ls_failed = false, noise_floor = false;
         if (!(gd < 0.0)) {
             ls_failed = true; // not a descent direction
@@ -634,17 +671,52 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
             if (constrained) {
                 if (iter == 0) stpmx = 1.0;
                 else {
-                    for (int i = 0; i < n; ++i) {
-                        const double a1 = d[i];
-                        if (nbd[i] == 0) continue;
-                        if (a1 < 0.0 && has_lower(nbd[i])) {
-                            const double a2 = l[i] - x[i];
-                            if (a2 >= 0.0) stpmx = 0.0;
-                            else if (a1 * stpmx < a2) stpmx = a2 / a1;
-                        } else if (a1 > 0.0 && has_upper(nbd[i])) {
-                            const double a2 = u[i] - x[i];
-                            if (a2 <= 0.0) stpmx = 0.0;
-                            else if (a1 * stpmx > a2) stpmx = a2 / a1;
+                    // The Fortran's sequential rule (stpmx shrinks to a2/a1 whenever a1·stpmx passes a2) ends at the ratio of its
+                    // LAST update, which lies within rounding of the smallest ratio.  Pass 1 (branch-free, vectorised) finds that
+                    // minimum; pass 2 runs the sequential rule itself over the few variables whose ratio is within 1e-12 of it --
+                    // every other variable either never updates or is overwritten by one of these later (its ratio is larger by
+                    // far more than the rounding of the comparison), so the result is the sequential one bit for bit.
+                    double rmin = stpmx;
+                    bool at_bound = false;
+                    {
+                        const double* __restrict dp = d.data();
+                        const double* __restrict lp = l.data();
+                        const double* __restrict up = u.data();
+                        const double* __restrict xp = x;
+                        double* __restrict tp = t.data();                 // scratch: the ratios
+                        for (int i = 0; i < n; ++i) {
+                            const double a1 = dp[i];
+                            const double a2 = a1 < 0.0 ? lp[i] - xp[i] : up[i] - xp[i];      // (±inf where the bound does not exist)
+                            const double r = a1 != 0.0 ? a2 / a1 : kInf;                  // >= 0 inside the box; +inf: never binds
+                            tp[i] = r;
+                        }
+                        // min over the ratios (exact in any order; four independent chains instead of one 4-cycle-latency chain)
+                        double m0 = rmin, m1 = rmin, m2 = rmin, m3 = rmin;
+                        int i = 0;
+                        for (; i + 3 < n; i += 4) {
+                            m0 = tp[i] < m0 ? tp[i] : m0;
+                            m1 = tp[i + 1] < m1 ? tp[i + 1] : m1;
+                            m2 = tp[i + 2] < m2 ? tp[i + 2] : m2;
+                            m3 = tp[i + 3] < m3 ? tp[i + 3] : m3;
+                        }
+                        for (; i < n; ++i) m0 = tp[i] < m0 ? tp[i] : m0;
+                        rmin = std::min(std::min(m0, m1), std::min(m2, m3));
+                        at_bound = rmin <= 0.0;                           // a2 >= 0 with a1 < 0 (or a2 <= 0 with a1 > 0): already on the bound
+                    }
+                    if (at_bound) {
+                        stpmx = 0.0;
+                    } else {
+                        const double cut = rmin * (1.0 + 1e-12);
+                        for (int i = 0; i < n; ++i) {
+                            if (!(t[i] <= cut)) continue;
+                            const double a1 = d[i];
+                            if (a1 < 0.0) {
+                                const double a2 = l[i] - x[i];
+                                if (a1 * stpmx < a2) stpmx = a2 / a1;
+                            } else {
+                                const double a2 = u[i] - x[i];
+                                if (a1 * stpmx > a2) stpmx = a2 / a1;
+                            }
                         }
                     }
                 }
@@ -679,8 +751,7 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                     noise_floor = true;
                     break;
                 }
-                double gdn = 0.0;
-                for (int i = 0; i < n; ++i) gdn += g[i] * d[i];
+                const double gdn = dotn(g.data(), d.data(), n);
                 f = fnew;
                 task = ls.next(f, gdn, stp);
                 if (task == MoreThuente::kEvaluate &&
@@ -737,14 +808,11 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         }
 
         // ---------------- limited-memory update --------------------------------------------------
-        double sy = 0.0, yy = 0.0, sg_old = 0.0;
         for (int i = 0; i < n; ++i) {
             s[i] = x[i] - x_old[i];
             y[i] = g[i] - g_old[i];
-            sy += s[i] * y[i];
-            yy += y[i] * y[i];
-            sg_old += s[i] * g_old[i];
         }
+        const double sy = dotn(s.data(), y.data(), n), yy = dotn(y.data(), y.data(), n), sg_old = dotn(s.data(), g_old.data(), n);
         if (sy > kEps * (-sg_old)) mem.push(s, y, sy, yy); // else: curvature too small, skip
     }
 
