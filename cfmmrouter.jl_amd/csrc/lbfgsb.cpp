@@ -176,6 +176,11 @@ struct MoreThuente {
 // n is a few hundred and every iteration makes ~40 passes over length-n vectors: these loops are the
 // solver's cost.  Reassociation is allowed inside the dot products only (so that they vectorise);
 // nothing here feeds the bit-exact pool arithmetic.
+// Sums that feed the solver's DECISIONS at the noise floor of the dual value -- d'd of the Cauchy step, s'y / y'y / s'g of
+// the update, d'd / g'd of the line search -- are accumulated in index order like the Fortran's ddot: reassociating them is
+// harmless to ~1e-16 per sum, but on interior optima the run then stops at another point INSIDE the rounding noise (measured,
+// config 5 against the Fortran fixture: 9.1e-8 with these sums in order, 6e-7 … 1.6e-6 with any one of them vectorised;
+// round 6).  The W'x products and the Gram matrix (dotn / dot4n below) are reassociated: they only shape the model.
 inline double dotn(const double* a, const double* b, int n)
 {
 #pragma clang fp reassociate(on)
@@ -453,15 +458,15 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                 order.resize(n);
                 int* __restrict op = order.data();
                 int cand = 0;
-                for (int i = 0; i < n; ++i) {                         // (vectorised: selects only)
+                for (int i = 0; i < n; ++i) {
                     const double ti = tp[i];
                     const bool fx = ti <= 0.0;                        // at its bound with the gradient pushing outward
                     const double di = fx ? 0.0 : -gp[i];
                     fp_[i] = fx ? 1 : 0;
                     dp[i] = di;
+                    dtd += di * di;                                   // (in index order: see the note above dotn)
                     moving += di != 0.0 ? 1 : 0;
                 }
-                dtd = dotn(dp, dp, n);
                 for (int i = 0; i < n; ++i) {                         // the heap's candidates, in index order
                     op[cand] = i;
                     cand += (tp[i] > 0.0 && tp[i] < kInf) ? 1 : 0;
@@ -659,8 +664,12 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         }
 
         // ---------------- line search along d = z − x -------------------------------------------
-        for (int i = 0; i < n; ++i) d[i] = z[i] - x[i];
-        const double dnorm2 = dotn(d.data(), d.data(), n), gd = dotn(g.data(), d.data(), n);
+        double dnorm2 = 0.0, gd = 0.0;
+        for (int i = 0; i < n; ++i) {                                 // (in index order: see the note above dotn)
+            d[i] = z[i] - x[i];
+            dnorm2 += d[i] * d[i];
+            gd += g[i] * d[i];
+        }
         bool ls_failed = false, noise_floor = false;
         if (!(gd < 0.0)) {
             ls_failed = true; // not a descent direction
@@ -751,7 +760,8 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
                     noise_floor = true;
                     break;
                 }
-                const double gdn = dotn(g.data(), d.data(), n);
+                double gdn = 0.0;
+                for (int i = 0; i < n; ++i) gdn += g[i] * d[i];
                 f = fnew;
                 task = ls.next(f, gdn, stp);
                 if (task == MoreThuente::kEvaluate &&
@@ -808,11 +818,14 @@ LbfgsbResult lbfgsb_minimize(int n, double* x, const double* lower, const double
         }
 
         // ---------------- limited-memory update --------------------------------------------------
-        for (int i = 0; i < n; ++i) {
+        double sy = 0.0, yy = 0.0, sg_old = 0.0;
+        for (int i = 0; i < n; ++i) {                                 // (three sums in index order: see the note above dotn)
             s[i] = x[i] - x_old[i];
             y[i] = g[i] - g_old[i];
+            sy += s[i] * y[i];
+            yy += y[i] * y[i];
+            sg_old += s[i] * g_old[i];
         }
-        const double sy = dotn(s.data(), y.data(), n), yy = dotn(y.data(), y.data(), n), sg_old = dotn(s.data(), g_old.data(), n);
         if (sy > kEps * (-sg_old)) mem.push(s, y, sy, yy); // else: curvature too small, skip
     }
 
