@@ -506,3 +506,45 @@ def test_route_on_single_block_markets_armed_and_unarmed():
         np.testing.assert_array_equal(x, y)
     ref = orc.route_oracle(oracle_objective(cr.LinearNonnegative(c)), oracle_poolset([b], n), v0=np.ones(n))
     assert rel_to_max(res[0][1], ref["psi"]) <= 1e-6
+
+
+def test_single_block_markets_under_the_in_library_exchanges():
+    """A market small enough for the single-block geometry on a SHARDED context: the block's row is then only this rank's
+    share, so it goes through the fold (cfmm_set_peers: fold + gather, two ranks in one process here) or is written to d_out
+    and all-reduced behind the launch (RCCL, world 1) -- never published directly as if it were the market's."""
+    import torch
+    n = 16
+    market = [synth.product_pools(1800, n, seed=321)]
+    v = synth.sweep_prices(n, seed=322)
+    _, _, psi_o, acc_o = oracle_sweep(market, n, v)
+    from cfmmrouter_amd.dist import shard_batches
+    ranks = [cr.DeviceBackend(n, shard_batches(market, r, 2)) for r in range(2)]
+    try:
+        assert all(be.ctx.segments()[0]["grid"] == 1 for be in ranks)
+        bufs = [torch.zeros(4 * (n + 1), dtype=torch.float64, device="cuda") for _ in range(2)]
+        outs = [torch.zeros(n + 1, dtype=torch.float64, device="cuda") for _ in range(2)]
+        vt = torch.from_numpy(v).cuda()
+        torch.cuda.synchronize()
+        for seq in range(4):
+            for r, be in enumerate(ranks):
+                be.ctx.set_peers([b.data_ptr() for b in bufs], 2, r, seq)
+            for r, be in enumerate(ranks):
+                be.ctx.sweep_dev(vt.data_ptr(), outs[r].data_ptr(), seq % 2 == 0)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1])
+            got = outs[0].cpu().numpy()
+            assert rel_to_max(got[:n], psi_o) <= 1e-12 and abs(got[n] - acc_o) <= 1e-12 * abs(acc_o)
+    finally:
+        for be in ranks:
+            be.close()
+    be = cr.DeviceBackend(n, market)
+    try:
+        assert be.ctx.segments()[0]["grid"] == 1
+        psi0, acc0 = be.eval(v)
+        be.ctx.rccl_init_rank(be.ctx.rccl_unique_id(), 1, 0)
+        psi1, acc1 = be.eval(v)                                  # direct store to d_out, ncclAllReduce behind it (one rank: identity)
+        np.testing.assert_array_equal(psi1, psi0)
+        assert acc1 == acc0 and rel_to_max(psi1, psi_o) <= 1e-12
+        be.ctx.set_rccl_comm(None)
+    finally:
+        be.close()
