@@ -35,5 +35,30 @@ while time.perf_counter() < t_end:
         assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) and ra[2]["evaluations"] == rb[2]["evaluations"], "route mismatch"
         routes += 1
         evals += ra[2]["evaluations"]
+# round 6: the single-block geometry (one family, <= 2048 pools: the block publishes {Ψ, acc} itself) under the same regime --
+# pre-armed routes and granules straight from the sweep block, against the two-launch form with the plain paths
+small = [synth.product_pools(1500, 24, seed=11)]
+sa, sb_ = cr.DeviceBackend(24, small), cr.DeviceBackend(24, small)
+sb_.ctx.set_option("armed", 0); sb_.ctx.set_option("host_flag", 0)
+assert sa.ctx.segments()[0]["grid"] == 1
+cs = synth.linear_prices(24, seed=12)
+t_end = time.perf_counter() + budget / 3
+small_routes = small_evals = 0
+while time.perf_counter() < t_end:
+    for _ in range(200):
+        v = np.exp(rng.uniform(-0.3, 0.3, 24))
+        t0 = time.perf_counter(); pa = sa.eval(v); worst = max(worst, time.perf_counter() - t0)
+        pb = sb_.eval(v)
+        assert np.array_equal(pa[0], pb[0]) and pa[1] == pb[1], "single-block eval mismatch"
+        small_evals += 1
+    for _ in range(50):
+        v0 = np.exp(rng.uniform(-0.05, 0.05, 24)) * np.maximum(cs, 1.0)
+        t0 = time.perf_counter(); ra = sa.ctx.route(OBJ_LINEAR_NONNEGATIVE, cs, 0, v0=v0); worst = max(worst, time.perf_counter() - t0)
+        rb = sb_.ctx.route(OBJ_LINEAR_NONNEGATIVE, cs, 0, v0=v0)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), "single-block route mismatch"
+        small_routes += 1
+        small_evals += ra[2]["evaluations"]
+sa.close(); sb_.close()
+print(f"single-block soak ok: {small_evals} evaluations, {small_routes} routes, all bit-identical to the plain paths")
 print(f"soak ok: {evals} evaluations, {routes} routes in {budget:.0f} s, all bit-identical to the plain paths; slowest call {1e3 * worst:.2f} ms")
 a.close(); b.close()
