@@ -36,7 +36,8 @@ while time.perf_counter() < t_end:
         routes += 1
         evals += ra[2]["evaluations"]
 # round 6: the single-block geometry (one family, <= 2048 pools: the block publishes {Ψ, acc} itself) under the same regime --
-# pre-armed routes and granules straight from the sweep block, against the two-launch form with the plain paths
+# pre-armed routes and granules straight from the sweep block, against the same geometry on the plain paths (launch when
+# ready, stream wait + copy)
 small = [synth.product_pools(1500, 24, seed=11)]
 sa, sb_ = cr.DeviceBackend(24, small), cr.DeviceBackend(24, small)
 sb_.ctx.set_option("armed", 0); sb_.ctx.set_option("host_flag", 0)
