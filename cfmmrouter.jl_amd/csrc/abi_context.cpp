@@ -216,7 +216,7 @@ static int64_t* option_slot(cfmm_ctx* c, const char* key)
         {"fast_math", &c->opt_fast_math}, {"armed", &c->opt_armed}, {"arm_timeout_ms", &c->opt_arm_timeout_ms},
         {"cost_geomean", &c->opt_cost_geomean}, {"cost_univ3", &c->opt_cost_univ3}, {"host_flag", &c->opt_host_flag},
         {"stop_in_noise", &c->opt_stop_in_noise}, {"multi_threads", &c->opt_multi_threads},
-        {"dev_prices_in_window", &c->opt_dev_prices_in_window}, {"univ3_heads", &c->opt_univ3_heads}, {"direct_small", &c->opt_direct_small},
+        {"dev_prices_in_window", &c->opt_dev_prices_in_window}, {"univ3_heads", &c->opt_univ3_heads}, {"direct_small", &c->opt_direct_small}, {"stream_stores", &c->opt_stream_stores},
 #ifdef CFMM_TEST_HOOKS
         {"debug_stall_ms", &c->opt_debug_stall_ms},
 #endif
@@ -236,6 +236,8 @@ int cfmm_set_option(cfmm_ctx* c, const char* key, int64_t value)
         return fail(c, CFMM_ERR_INVALID_ARG, "block must be 0 (auto), %d or %d", kMidBlock, kBigBlock);
     if (slot == &c->opt_bin_copies && !(value == 0 || value == 1 || value == 2))
         return fail(c, CFMM_ERR_INVALID_ARG, "bin_copies must be 0 (auto), 1 (shared) or 2 (per wavefront)");
+    if (slot == &c->opt_stream_stores && !(value == 0 || value == 1 || value == 2))
+        return fail(c, CFMM_ERR_INVALID_ARG, "stream_stores must be 0 (auto), 1 (write-through) or 2 (non-temporal)");
     *slot = value;
     if (slot != &c->opt_multi_threads)
         for (cfmm_ctx* child : c->shards) {

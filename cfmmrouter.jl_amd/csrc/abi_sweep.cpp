@@ -280,6 +280,9 @@ int ensure_geometry(cfmm_ctx* c)
     }
     c->rows_total = rows;
     c->m_total = trades;
+    c->touched_bytes = 0;
+    for (const auto& s : c->segs)   // bytes read per pool in the packed layout + one 16-byte trade record (a lower bound for multi-tick UniV3)
+        c->touched_bytes += s.m * (int64_t)(s.kind == CFMM_KIND_PRODUCT ? 24 + 16 : s.kind == CFMM_KIND_GEOMEAN ? 48 + 16 : (s.has_walk ? 104 : 56) + 16);
     if (rows > c->rows_cap) {
         (void)hipFree(c->d_partials);
         c->d_partials = nullptr;
@@ -365,6 +368,7 @@ int enqueue_sweep(cfmm_ctx* c, const double* d_v, double* d_out, bool materializ
         // equally long turns a stalled host into a slow evaluation on every rank instead of a failed route on all of them
         if (sharded) a.arm_timeout = std::max<long long>(a.arm_timeout, c->peer_timeout_ticks);
         a.flags = c->d_stage ? reinterpret_cast<unsigned long long*>(c->d_stage + c->flag_off) : nullptr;
+        a.nt_stores = c->opt_stream_stores == 2 || (c->opt_stream_stores == 0 && c->touched_bytes > (int64_t)256 << 20) ? 1 : 0;
         if (direct) {
             a.direct = 1;
             a.direct_out = d_out;

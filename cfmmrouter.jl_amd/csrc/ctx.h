@@ -118,6 +118,7 @@ struct cfmm_ctx {
     std::vector<cfmm::Segment> segs;
     std::vector<cfmm::Group> groups;
     int64_t m_total = 0;
+    int64_t touched_bytes = 0;    // what one materialising sweep moves by construction (packed layout; ensure_geometry): decides "stream_stores" = auto
     int64_t rows_total = 0;
 
     double* d_v = nullptr;        // [n]
@@ -198,6 +199,9 @@ struct cfmm_ctx {
     int64_t opt_stop_in_noise = 0; // cfmm_route: 1 = end the run when a line-search trial point sits on the rounding-noise floor
                                    //    (LbfgsbOptions::stop_in_noise; fewer evaluations, departs from L-BFGS-B 3.0); 0 = reference behaviour
     int64_t opt_multi_threads = 1;
+    int64_t opt_stream_stores = 0; // trade-record stores: 0 = auto (non-temporal when one sweep touches more than the 256 MiB Infinity Cache,
+                                   //    i.e. the pool state cannot stay cache-resident between sweeps; write-through otherwise), 1 = always
+                                   //    write-through, 2 = always non-temporal (a caller that rotates over many markets says so)
     int64_t opt_direct_small = 1;  // 1: single-family markets of up to kDirectPools pools are swept by ONE block that publishes {Ψ, acc}
                                    //    itself (no fold launch); 0: the general two-launch geometry
     int64_t opt_univ3_heads = 1;   // 1: multi-tick UniV3 walks decide their first four list ticks from the per-pool float threshold heads

@@ -720,10 +720,14 @@ using UniV3OpsLean = UniV3OpsT<false>;
 // cannot see through inline asm -- and the values stored here are selects computed right before the next store, so the
 // next v_cndmask may land in the registers of this one (found as 9 % wrong rows in the two-row trade layout).
 typedef double d2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_pair(double2* dst, double x, double y)
+// nt (SweepArgs::nt_stores, launch-uniform): non-temporal instead of write-through -- for markets whose pool state comes from
+// HBM on every sweep (too large for the Infinity Cache, or a caller that rotates over many markets): the trade lines then
+// bypass the cache hierarchy instead of displacing pool state that is about to be read.
+__device__ __forceinline__ void store_pair(double2* dst, double x, double y, int nt)
 {
     d2v val = {x, y};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(val) : "memory");
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(val) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(val) : "memory");
 }
 
 // Partial rows are written through as well: no dirty line is left for the end-of-kernel release in front of the fold
@@ -898,10 +902,10 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
         const bool d1 = dir == kDir1;
         if (MAT) {
             if (a.compact) {
-                store_pair(a.Delta + i, d1 ? d : -d, l);   // {+Δ₁, Λ₂} or {−Δ₂, Λ₁}: the sign bit carries the direction
+                store_pair(a.Delta + i, d1 ? d : -d, l, a.nt_stores);   // {+Δ₁, Λ₂} or {−Δ₂, Λ₁}: the sign bit carries the direction
             } else {
-                store_pair(a.Delta + i, d1 ? d : 0.0, d1 ? 0.0 : d);
-                store_pair(a.Lambda + i, d1 ? 0.0 : l, d1 ? l : 0.0);
+                store_pair(a.Delta + i, d1 ? d : 0.0, d1 ? 0.0 : d, a.nt_stores);
+                store_pair(a.Lambda + i, d1 ? 0.0 : l, d1 ? l : 0.0, a.nt_stores);
             }
         }
         acc += l * (d1 ? v2 : v1) - d * (d1 ? v1 : v2);
@@ -917,10 +921,10 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
     if (dir == kDirNone) {
         if (MAT) {
             if (a.compact) {
-                store_pair(a.Delta + i, 0.0, 0.0);
+                store_pair(a.Delta + i, 0.0, 0.0, a.nt_stores);
             } else {
-                store_pair(a.Delta + i, 0.0, 0.0);
-                store_pair(a.Lambda + i, 0.0, 0.0);
+                store_pair(a.Delta + i, 0.0, 0.0, a.nt_stores);
+                store_pair(a.Lambda + i, 0.0, 0.0, a.nt_stores);
             }
         }
         if constexpr (GBINS) a.gflow[i] = make_double2(0.0, 0.0);
@@ -950,10 +954,10 @@ __device__ __forceinline__ void process_pool(const Ops& ops, const SweepArgs& a,
                     rb = -1.0;
                 }
             }
-            store_pair(a.Delta + i, ra, rb);
+            store_pair(a.Delta + i, ra, rb, a.nt_stores);
         } else {
-            store_pair(a.Delta + i, t.d1, t.d2);
-            store_pair(a.Lambda + i, t.l1, t.l2);
+            store_pair(a.Delta + i, t.d1, t.d2, a.nt_stores);
+            store_pair(a.Lambda + i, t.l1, t.l2, a.nt_stores);
         }
     }
     // src/router.jl:82  dot(Λ, v[Ai]) - dot(Δ, v[Ai])

@@ -91,6 +91,15 @@ int cfmm_reset_stream(cfmm_ctx* ctx);
  *                     materialising sweep stores ONE 16-byte record per pool -- {+Delta1, Lambda2} or {-Delta2,
  *                     Lambda1}, a two-coin trade has one direction -- plus overflow rows for pools whose four values
  *                     do not fit that form; cfmm_get_trades* / cfmm_trades_dev return the reference's rows bit for bit),
+ *                     "stream_stores" (trade records leave through 0 = auto: non-temporal stores when one sweep touches more
+ *                     than the 256 MiB Infinity Cache -- the pool state then comes from HBM on every sweep and the trade lines
+ *                     should not displace it: -4 % at 8M-16M pools -- and write-through stores otherwise; 1 = always
+ *                     write-through (best while the market stays cache-resident between sweeps: route!); 2 = always
+ *                     non-temporal: a caller that rotates over many markets, each of which fits the cache, says so: -2..-5 %
+ *                     when the pool state really comes from HBM, +0..3 % when it does not),
+ *                     "direct_small" (default 1: a context with one pool family and at most 2048 pools is swept by ONE block
+ *                     that delivers {psi, acc} itself -- one kernel per evaluation instead of sweep + fold; 0: the general
+ *                     two-launch geometry),
  *                     "univ3_heads" (default 1: multi-tick UniV3 walks decide their first four list ticks from a per-pool
  *                     head of rounded-down binary32 thresholds read with the pool's coalesced streams, and consult the
  *                     exact threshold array only for deeper walks or a price within 2^-23 of a threshold: same decisions,

@@ -548,3 +548,35 @@ def test_single_block_markets_under_the_in_library_exchanges():
         be.ctx.set_rccl_comm(None)
     finally:
         be.close()
+
+
+def test_trade_store_policy_changes_no_bit():
+    """Option stream_stores (write-through / non-temporal trade-record stores; auto by market size): a cache policy, nothing
+    else -- trades (compact records, overflow rows, plain rows), psi and the dual value are identical bit for bit."""
+    n = 40
+    batches = [synth.product_pools(70_000, n, seed=801), synth.geomean_pools(30_000, n, seed=802),
+               synth.univ3_pools(8_000, n, 5, seed=803)]
+    batches[1].γ[::7] = 1.01                                   # fee > 1: both directions trade -> overflow rows
+    v = synth.sweep_prices(n, seed=804, spread=0.4)
+    ref = None
+    for compact in (1, 0):
+        for policy in (1, 2, 0):
+            be = cr.DeviceBackend(n, batches)
+            be.ctx.set_option("compact_trades", compact)
+            be.ctx.set_option("stream_stores", policy)
+            be.ctx.set_option("alternate", 0)
+            try:
+                psi, acc = be.find_arb(v)
+                D, L = be.trades()
+            finally:
+                be.close()
+            if ref is None:
+                ref = (psi, acc, D, L)
+            np.testing.assert_array_equal(psi, ref[0])
+            assert acc == ref[1]
+            np.testing.assert_array_equal(D, ref[2])
+            np.testing.assert_array_equal(L, ref[3])
+    Do, Lo, psi_o, _ = oracle_sweep(batches, n, v)
+    np.testing.assert_array_equal(ref[2][:70_000], Do[:70_000])
+    np.testing.assert_array_equal(ref[2][100_000:], Do[100_000:])
+    assert rel_to_max(ref[0], psi_o) <= 1e-12
