@@ -1,3 +1,6 @@
+"""A/B of the trade-store policy (option stream_stores: 1 write-through, 2 non-temporal, 0 auto by size) on 8M / 16M ProductTwoCoin
+pools, HBM-resident by size (ring of 3 / 2 market copies): sweep-kernel span by CP events, step wall clock, fraction of the bus over the
+40 B per pool the layout moves.  profiles/r06_ab_stream_stores.txt.  usage: python scripts/atscale_stores.py"""
 import sys, os, time; sys.path.insert(0, os.getcwd())
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG","1")
 import numpy as np, torch, cfmmrouter_amd as cr

@@ -1,3 +1,6 @@
+"""cfmm_route on the six BASELINE-size workloads against the Fortran L-BFGS-B fixture (tests/golden/route_fortran.npz): evaluations and
+max|dPsi| / max|Psi|.  Round 6 used it to find which of the solver's sums may be reassociated without moving the stopping point of the
+interior-optimum markets inside the rounding noise (csrc/lbfgsb.cpp, note above dotn).  usage: python scripts/seqtest.py"""
 import sys, os, json, numpy as np
 sys.path.insert(0, os.getcwd())
 import cfmmrouter_amd as cr
