@@ -142,7 +142,7 @@ struct SweepArgs {
     // Single-block launches (grid == 1: markets of up to kDirectPools pools, one family): the block's row IS the result, so
     // it goes straight to `direct_out` (device consumers) or -- direct_host.gran set -- to the host as granules, and NO fold
     // launch follows: one kernel per evaluation instead of two (the reference's own benchmark grid, benchmark/scaling.jl:8-38,
-    // is all markets of this size, where an evaluation is launch latency and nothing else).
+    // has six of its ten market sizes in this range, where an evaluation is launch latency and nothing else).
     int nt_stores;               // 1: trade records leave through non-temporal stores (HBM-resident markets); 0: write-through
     int direct;
     double* direct_out;          // [n + 1] {Ψ, acc}

@@ -422,8 +422,7 @@ def _small_market(kind, m, n, seed):
 @pytest.mark.parametrize("kind", ["product", "geomean", "bounded", "univ3"])
 @pytest.mark.parametrize("m", [1, 100, 1500, 2048, 2049])
 def test_single_block_markets_publish_their_result_without_a_fold(kind, m):
-    """Markets of up to 2048 pools of one family (the reference's own benchmark grid, benchmark/scaling.jl:8-38, is all this
-    size) are swept by ONE 1024-thread block whose row IS the result: it goes straight to the host granules / the device
+    """Markets of up to 2048 pools of one family (six of the ten sizes of the reference's own benchmark grid, benchmark/scaling.jl:8-38) are swept by ONE 1024-thread block whose row IS the result: it goes straight to the host granules / the device
     output, and no fold launch follows (option direct_small, default on; 2049 pools: the general two-launch geometry).
     Same trades bit for bit as the two-launch form and as the CPU restatement; Ψ to summation-order rounding; host-pointer
     and device-pointer sweeps, fused and materialising, 50 price vectors back to back."""
